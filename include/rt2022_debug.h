@@ -1,0 +1,24 @@
+/*
+ * rt2022_debug.h — probe entry points of librt2022.so used by the parity tests:
+ * they run pieces of the device arithmetic (rt_math.h, the path RNG) on the GPU so
+ * that tests can compare them bit for bit with the CPU oracle. Not part of the
+ * drop-in boundary.
+ */
+#ifndef RT2022_DEBUG_H
+#define RT2022_DEBUG_H
+#include "rt2022.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* op: 0 sin, 1 cos, 2 acos, 3 atan2(a,b), 4 log, 5 sqrt, 6 a/b. Host buffers. */
+int rt_debug_math_device(int op, const double *a, const double *b, double *out, uint64_t n);
+/* n draws from Rng(state): mode 0 next_u64, 1 gen_f64 (bits), 2 gen_range(lo,hi) (bits), 3 gen_index(bound). */
+int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n);
+/* Traversal-stack entries the scene needs and the persistent grid size used for it. */
+int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

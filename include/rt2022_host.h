@@ -1,0 +1,60 @@
+/*
+ * rt2022_host.h — C ABI over the host-side scene layer (the C++ mirror of the
+ * reference's scene-builder surface, raytracer_2022_amd/csrc/host/scene_api.hpp).
+ *
+ * These are the callers' side of the hot path: what
+ * raytracer/src/main.rs:43-99 does before the render threads start —
+ * Camera::new, scene::<name>(), BvhNode::new_list(&world, t0, t1), the row
+ * shuffle — producing the rt_scene_desc / rt_camera / row list that
+ * include/rt2022.h consumes. Pure host code: usable without a GPU.
+ */
+#ifndef RT2022_HOST_H
+#define RT2022_HOST_H
+#include "rt2022.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtb_scene rtb_scene;   /* a built scene: owns the pools behind its rt_scene_desc */
+
+/* scene::<name>() + BvhNode::new_list (main.rs:89-90) with a seeded stream.
+ * name: random_scene | two_spheres | two_perlin_spheres | earth | simple_light |
+ *       cornell_box | cornell_smoke | final_scene | wwscene (scene.rs:22-571).
+ * assets_dir: where <stem>.ppm textures / Shuttle.obj live (NULL or "" = procedural
+ * stand-ins). param: random_scene → half grid size (0 = 11, the reference's);
+ * wwscene → midpoint-subdivision levels of the model mesh. */
+int rtb_scene_build(const char *name, uint64_t seed, const char *assets_dir, int32_t param, rtb_scene **out);
+void rtb_scene_free(rtb_scene *scene);
+const rt_scene_desc *rtb_scene_desc(const rtb_scene *scene);
+/* The view the scene is meant to be rendered with (camera constants of main.rs:43-51
+ * for wwscene; the RTIOW book values otherwise). */
+int rtb_scene_default_view(const rtb_scene *scene, double aspect_ratio, rt_camera *cam, double background[3]);
+
+/* Camera::new (basic/camera.rs:24-62). */
+int rtb_camera_new(const double lookfrom[3], const double lookat[3], const double vup[3], double vfov,
+                   double aspect_ratio, double aperture, double focus_dist, double time0, double time1,
+                   rt_camera *out);
+/* main.rs:93-99: Fisher-Yates shuffled line ids 0..image_height. */
+int rtb_shuffled_rows(uint32_t image_height, uint64_t seed, uint32_t *out_rows);
+
+/* BvhNode::new_list over `n` leaf refs with boxes6[i] = {min[3], max[3]} (used for
+ * both bounding_box(0,0) and (t0,t1)) — exposes the builder for known-answer
+ * tests. Writes up to max_nodes nodes (DFS order, root = 0) and returns the node
+ * count, or a negative error. */
+int rtb_bvh_build(const uint32_t *leaf_refs, const double *boxes6, uint32_t n, uint64_t seed,
+                  rt_bvh_node *out_nodes, uint32_t max_nodes);
+
+/* Image output (main.rs:191-201): place the row sums (row_ids order) at
+ * (x, H-1-y) of an RGB8 image through write_color. rgb8 = width*height*3 bytes. */
+int rtb_fill_image(const double *rgb_sum, const uint32_t *row_ids, uint32_t n_rows, uint32_t width,
+                   uint32_t height, int32_t spp, uint8_t *rgb8);
+int rtb_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
+const char *rtb_last_error(void);
+/* sizeof of each ABI structure (binding layout check); returns how many there are. */
+int rtb_abi_sizes(uint32_t *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

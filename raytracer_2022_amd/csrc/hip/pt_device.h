@@ -1,0 +1,75 @@
+// pt_device.h — device-side views of the flattened scene and the launch interface
+// between rt_api.hip (C ABI, validation, HBM residency) and pt_kernel.hip (kernels).
+#ifndef RT2022_PT_DEVICE_H
+#define RT2022_PT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/rt2022.h"
+
+namespace rt2022 {
+
+// Pointers into HBM, one pool per kind (layouts = include/rt2022.h).
+struct SceneDev {
+    const rt_bvh_node *nodes;
+    const rt_sphere *spheres;
+    const rt_moving_sphere *moving_spheres;
+    const rt_rect *rects;
+    const rt_box *boxes;
+    const rt_triangle *triangles;
+    const rt_ring *rings;
+    const rt_medium *media;
+    const rt_xform *xforms;
+    const rt_list *lists;
+    const uint32_t *list_items;
+    const uint32_t *lights;
+    const rt_material *materials;
+    const rt_texture *textures;
+    const rt_image *images;
+    const uint8_t *image_data;
+    const rt_perlin *perlins;
+    uint32_t root;
+    uint32_t n_lights;
+};
+
+// Counter block in HBM (same order as rt_stats' integer fields).
+struct StatsDev {
+    unsigned long long paths, rays, node_visits;
+    unsigned long long prim_tests[RT_KIND_COUNT];
+    unsigned long long light_pdf_tests, rng_draws;
+};
+
+struct RenderArgs {
+    rt_camera cam;
+    uint32_t width, height, spp, max_depth;
+    uint32_t n_frames, n_rows;
+    uint32_t chunk, n_chunks;          // samples per work item, items per pixel
+    double background[3];
+    double t_min;
+    uint64_t seed;
+    uint64_t n_pixels;                 // n_rows * width
+    uint64_t n_items;                  // n_pixels * n_chunks
+    const uint32_t *row_ids;           // device
+    double *partial;                   // [n_chunks][n_pixels][3] (== out when n_chunks == 1)
+    unsigned long long *work_counter;  // zeroed before launch
+    StatsDev *stats;                   // may be null
+};
+
+// Traversal-stack capacities the megakernel is instantiated for.
+constexpr int kStackSmall = 24;
+constexpr int kStackLarge = 64;
+constexpr int kBlock = 256;
+
+// Launchers (pt_kernel.hip). `stack_need` = entries the scene needs (host-computed).
+hipError_t launch_render(const SceneDev &scene, const RenderArgs &args, uint32_t stack_need, bool counters,
+                         int n_blocks_hint, hipStream_t stream);
+hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
+hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
+hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
+hipError_t launch_rng_probe(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n, hipStream_t stream);
+// Occupancy-derived persistent grid size for the given variant.
+int render_grid_blocks(uint32_t stack_need, bool counters);
+
+} // namespace rt2022
+#endif

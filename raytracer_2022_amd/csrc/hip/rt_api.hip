@@ -1,0 +1,478 @@
+// rt_api.hip — the device half of the C ABI (include/rt2022.h): scene validation,
+// HBM residency, launches. No CPU fallback exists: every entry point here needs a
+// HIP device and reports RT_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/rt2022.h"
+#include "../../../include/rt2022_debug.h"
+#include "../host/rt_error.hpp"
+#include "pt_device.h"
+
+using namespace rt2022;
+
+namespace {
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+#define RT_REQUIRE(cond, code, msg) do { if (!(cond)) throw Fail{code, msg}; } while (0)
+#define RT_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Fail{RT_ERR_DEVICE, std::string(#expr ": ") + hipGetErrorString(e_)}; } while (0)
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const Fail &e) {
+        set_error(e.msg);
+        return e.code;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
+// ---- validation -------------------------------------------------------------------
+struct Validator {
+    const rt_scene_desc &d;
+    std::vector<int32_t> node_need;      // memo: stack need of each node (-1 unknown, -2 on the DFS stack)
+    std::vector<int32_t> node_xdepth;
+    explicit Validator(const rt_scene_desc &desc) : d(desc), node_need(desc.n_nodes, -1), node_xdepth(desc.n_nodes, 0) {}
+
+    uint32_t pool_size(uint32_t kind) const {
+        switch (kind) {
+            case RT_KIND_NODE: return d.n_nodes;
+            case RT_KIND_SPHERE: return d.n_spheres;
+            case RT_KIND_MOVING_SPHERE: return d.n_moving_spheres;
+            case RT_KIND_RECT: return d.n_rects;
+            case RT_KIND_BOX: return d.n_boxes;
+            case RT_KIND_TRIANGLE: return d.n_triangles;
+            case RT_KIND_RING: return d.n_rings;
+            case RT_KIND_MEDIUM: return d.n_media;
+            case RT_KIND_TRANSLATE: case RT_KIND_ROTATE_Y: case RT_KIND_ZOOM: return d.n_xforms;
+            case RT_KIND_LIST: return d.n_lists;
+            default: return 0;
+        }
+    }
+    void check_ref(uint32_t ref, const char *where) const {
+        uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
+        RT_REQUIRE(kind < RT_KIND_COUNT, RT_ERR_INVALID, std::string(where) + ": ref with unknown kind");
+        RT_REQUIRE(idx < pool_size(kind), RT_ERR_INVALID, std::string(where) + ": ref index out of range");
+        if (kind >= RT_KIND_TRANSLATE && kind <= RT_KIND_ZOOM)
+            RT_REQUIRE(d.xforms[idx].kind == kind, RT_ERR_INVALID, std::string(where) + ": mover ref kind does not match its record");
+    }
+    void check_mat(uint32_t mat, const char *where) const {
+        RT_REQUIRE(mat < d.n_materials, RT_ERR_INVALID, std::string(where) + ": material index out of range");
+    }
+
+    void check_pools() const {
+#define RT_NONNULL(n, p) RT_REQUIRE(d.n == 0 || d.p != nullptr, RT_ERR_INVALID, #p " is null but " #n " > 0")
+        RT_NONNULL(n_nodes, nodes); RT_NONNULL(n_spheres, spheres); RT_NONNULL(n_moving_spheres, moving_spheres);
+        RT_NONNULL(n_rects, rects); RT_NONNULL(n_boxes, boxes); RT_NONNULL(n_triangles, triangles); RT_NONNULL(n_rings, rings);
+        RT_NONNULL(n_media, media); RT_NONNULL(n_xforms, xforms); RT_NONNULL(n_lists, lists); RT_NONNULL(n_list_items, list_items);
+        RT_NONNULL(n_lights, lights); RT_NONNULL(n_materials, materials); RT_NONNULL(n_textures, textures);
+        RT_NONNULL(n_images, images); RT_NONNULL(image_data_bytes, image_data); RT_NONNULL(n_perlins, perlins);
+#undef RT_NONNULL
+        for (uint32_t i = 0; i < d.n_nodes; i++) { check_ref(d.nodes[i].left, "node.left"); check_ref(d.nodes[i].right, "node.right"); }
+        for (uint32_t i = 0; i < d.n_spheres; i++) check_mat(d.spheres[i].mat, "sphere");
+        for (uint32_t i = 0; i < d.n_moving_spheres; i++) check_mat(d.moving_spheres[i].mat, "moving_sphere");
+        for (uint32_t i = 0; i < d.n_rects; i++) { check_mat(d.rects[i].mat, "rect"); RT_REQUIRE(d.rects[i].axis <= RT_RECT_YZ, RT_ERR_INVALID, "rect: bad axis"); }
+        for (uint32_t i = 0; i < d.n_boxes; i++) check_mat(d.boxes[i].mat, "box");
+        for (uint32_t i = 0; i < d.n_triangles; i++) check_mat(d.triangles[i].mat, "triangle");
+        for (uint32_t i = 0; i < d.n_rings; i++) check_mat(d.rings[i].mat, "ring");
+        for (uint32_t i = 0; i < d.n_media; i++) {
+            check_mat(d.media[i].mat, "medium");
+            RT_REQUIRE(d.materials[d.media[i].mat].kind == RT_MAT_ISOTROPIC, RT_ERR_INVALID, "medium: phase function must be Isotropic");
+            check_ref(d.media[i].boundary, "medium.boundary");
+            // Device path: movers around one primitive (see rt_medium in rt2022.h).
+            uint32_t ref = d.media[i].boundary;
+            int lvl = 0;
+            while (RT_REF_KIND(ref) >= RT_KIND_TRANSLATE && RT_REF_KIND(ref) <= RT_KIND_ZOOM) {
+                RT_REQUIRE(++lvl <= RT_MAX_XFORM_DEPTH, RT_ERR_UNSUPPORTED, "medium: boundary nested under too many movers");
+                ref = d.xforms[RT_REF_INDEX(ref)].child;
+                check_ref(ref, "medium.boundary chain");
+            }
+            uint32_t k = RT_REF_KIND(ref);
+            RT_REQUIRE(k >= RT_KIND_SPHERE && k <= RT_KIND_RING, RT_ERR_UNSUPPORTED,
+                       "medium: boundary must be a primitive, optionally under movers");
+        }
+        for (uint32_t i = 0; i < d.n_xforms; i++) {
+            uint32_t k = d.xforms[i].kind;
+            RT_REQUIRE(k >= RT_KIND_TRANSLATE && k <= RT_KIND_ZOOM, RT_ERR_INVALID, "xform: bad kind");
+            check_ref(d.xforms[i].child, "xform.child");
+        }
+        for (uint32_t i = 0; i < d.n_lists; i++)
+            RT_REQUIRE((uint64_t)d.lists[i].first + d.lists[i].count <= d.n_list_items, RT_ERR_INVALID, "list: items out of range");
+        for (uint32_t i = 0; i < d.n_list_items; i++) check_ref(d.list_items[i], "list item");
+        for (uint32_t i = 0; i < d.n_lights; i++) check_ref(d.lights[i], "light");
+        for (uint32_t i = 0; i < d.n_materials; i++) {
+            const rt_material &m = d.materials[i];
+            RT_REQUIRE(m.kind <= RT_MAT_ISOTROPIC, RT_ERR_INVALID, "material: bad kind");
+            if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC)
+                RT_REQUIRE(m.tex < d.n_textures, RT_ERR_INVALID, "material: texture index out of range");
+        }
+        for (uint32_t i = 0; i < d.n_textures; i++) {
+            const rt_texture &t = d.textures[i];
+            RT_REQUIRE(t.kind <= RT_TEX_IMAGE, RT_ERR_INVALID, "texture: bad kind");
+            if (t.kind == RT_TEX_CHECKER) RT_REQUIRE(t.a < d.n_textures && t.b < d.n_textures, RT_ERR_INVALID, "checker: child out of range");
+            if (t.kind == RT_TEX_NOISE) RT_REQUIRE(t.a < d.n_perlins, RT_ERR_INVALID, "noise: perlin index out of range");
+            if (t.kind == RT_TEX_IMAGE) RT_REQUIRE(t.a < d.n_images, RT_ERR_INVALID, "image texture: image index out of range");
+        }
+        for (uint32_t i = 0; i < d.n_images; i++) {
+            const rt_image &im = d.images[i];
+            RT_REQUIRE(im.offset + (uint64_t)im.width * im.height * 3 <= d.image_data_bytes, RT_ERR_INVALID, "image: data out of range");
+        }
+        for (uint32_t i = 0; i < d.n_perlins; i++)
+            for (int k = 0; k < 256; k++) {
+                const rt_perlin &p = d.perlins[i];
+                RT_REQUIRE((uint32_t)p.perm_x[k] < 256 && (uint32_t)p.perm_y[k] < 256 && (uint32_t)p.perm_z[k] < 256, RT_ERR_INVALID, "perlin: permutation entry out of range");
+            }
+    }
+
+    // Stack entries trace<> needs while processing `ref` (its own slot included), and
+    // the deepest nesting of movers below it. Cycles are rejected.
+    void need(uint32_t ref, int depth, int32_t &out_need, int32_t &out_xdepth) {
+        RT_REQUIRE(depth < 4096, RT_ERR_UNSUPPORTED, "scene graph too deep");
+        uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
+        if (kind == RT_KIND_NODE) {
+            RT_REQUIRE(!(ref & RT_REF_FLIP), RT_ERR_UNSUPPORTED, "FlipFace directly on a BvhNode ref: push the flip down to the leaves");
+            RT_REQUIRE(node_need[idx] != -2, RT_ERR_INVALID, "cycle in the BVH");
+            if (node_need[idx] >= 0) { out_need = node_need[idx]; out_xdepth = node_xdepth[idx]; return; }
+            node_need[idx] = -2;
+            int32_t nl, xl, nr, xr;
+            need(d.nodes[idx].left, depth + 1, nl, xl);
+            if (d.nodes[idx].right == d.nodes[idx].left) { nr = nl; xr = xl; }
+            else need(d.nodes[idx].right, depth + 1, nr, xr);
+            out_need = std::max(1 + nl, nr);
+            out_xdepth = std::max(xl, xr);
+            node_need[idx] = out_need;
+            node_xdepth[idx] = out_xdepth;
+            return;
+        }
+        if (kind >= RT_KIND_TRANSLATE && kind <= RT_KIND_ZOOM) {
+            int32_t nc, xc;
+            need(d.xforms[idx].child, depth + 1, nc, xc);
+            out_need = 1 + nc;
+            out_xdepth = 1 + xc;
+            return;
+        }
+        if (kind == RT_KIND_LIST) {
+            RT_REQUIRE(!(ref & RT_REF_FLIP), RT_ERR_UNSUPPORTED, "FlipFace directly on a HittableList ref: push the flip down to the items");
+            const rt_list &l = d.lists[idx];
+            int32_t best = std::max<int32_t>(1, (int32_t)l.count), bx = 0;
+            for (uint32_t i = 0; i < l.count; i++) {
+                int32_t ni, xi;
+                need(d.list_items[l.first + i], depth + 1, ni, xi);
+                best = std::max(best, (int32_t)(l.count - 1 - i) + ni);
+                bx = std::max(bx, xi);
+            }
+            out_need = best;
+            out_xdepth = bx;
+            return;
+        }
+        out_need = 1;
+        out_xdepth = 0;
+    }
+};
+
+template <class T>
+T *upload(const T *src, uint64_t n, std::vector<void *> &owned) {
+    // Never hand the kernels a null pool: an empty pool gets one zeroed element.
+    uint64_t bytes = (n ? n : 1) * sizeof(T);
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    owned.push_back(p);
+    if (n) RT_HIP(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    else RT_HIP(hipMemset(p, 0, bytes));
+    return (T *)p;
+}
+
+struct Workspace {
+    unsigned long long *work_counter = nullptr;
+    StatsDev *stats = nullptr;
+    double *partial = nullptr;
+    uint64_t partial_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rt_stats *pending = nullptr;      // host stats to fill at rt_render_wait
+    bool pending_counters = false;
+};
+
+} // namespace
+
+struct rt_scene {
+    SceneDev dev{};
+    std::vector<void *> owned;
+    uint32_t stack_need = 1;
+    int device = 0;
+    std::mutex mu;
+    std::map<hipStream_t, Workspace> ws;
+};
+
+namespace {
+
+Workspace &workspace_for(rt_scene *sc, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(sc->mu);
+    Workspace &w = sc->ws[stream];
+    if (!w.work_counter) {
+        RT_HIP(hipMalloc((void **)&w.work_counter, sizeof(unsigned long long)));
+        RT_HIP(hipMalloc((void **)&w.stats, sizeof(StatsDev)));
+        RT_HIP(hipEventCreate(&w.ev0));
+        RT_HIP(hipEventCreate(&w.ev1));
+    }
+    return w;
+}
+
+void check_params(const rt_scene *scene, const rt_camera *cam, const rt_params *p) {
+    RT_REQUIRE(scene && cam && p, RT_ERR_INVALID, "null argument");
+    RT_REQUIRE(p->width > 0 && p->height > 0 && p->n_frames > 0, RT_ERR_INVALID, "empty image");
+    RT_REQUIRE(cam->time0 < cam->time1, RT_ERR_INVALID, "camera time0 >= time1 (gen_range panics in the reference, camera.rs:71)");
+    RT_REQUIRE(p->n_rows == 0 || p->row_ids, RT_ERR_INVALID, "row_ids is null");
+    RT_REQUIRE((uint64_t)p->height * p->n_frames <= 0xFFFFFFFFull, RT_ERR_INVALID, "height * n_frames overflows a row id");
+}
+
+// Enqueue one render on `stream`; row ids and output are device pointers.
+void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint32_t *d_rows, double *d_out,
+             hipStream_t stream, rt_stats *stats) {
+    Workspace &w = workspace_for(sc, stream);
+    RenderArgs a{};
+    a.cam = *cam;
+    a.width = p->width; a.height = p->height; a.spp = p->spp; a.max_depth = p->max_depth;
+    a.n_frames = p->n_frames; a.n_rows = p->n_rows;
+    uint32_t chunk = (p->spp_chunk == 0 || p->spp_chunk > p->spp) ? p->spp : p->spp_chunk;
+    if (chunk == 0) chunk = 1;
+    a.chunk = chunk;
+    a.n_chunks = p->spp == 0 ? 1 : (p->spp + chunk - 1) / chunk;
+    std::memcpy(a.background, p->background, sizeof a.background);
+    a.t_min = p->t_min;
+    a.seed = p->seed;
+    a.n_pixels = (uint64_t)p->n_rows * p->width;
+    a.n_items = a.n_pixels * a.n_chunks;
+    a.row_ids = d_rows;
+    bool counters = stats && (p->flags & RT_FLAG_COUNTERS);
+    if (a.n_chunks > 1) {
+        uint64_t bytes = a.n_items * 3 * sizeof(double);
+        if (bytes > w.partial_bytes) {
+            RT_HIP(hipStreamSynchronize(stream));
+            if (w.partial) RT_HIP(hipFree(w.partial));
+            w.partial = nullptr; w.partial_bytes = 0;
+            RT_HIP(hipMalloc((void **)&w.partial, bytes));
+            w.partial_bytes = bytes;
+        }
+        a.partial = w.partial;
+    } else {
+        a.partial = d_out;
+    }
+    a.work_counter = w.work_counter;
+    a.stats = counters ? w.stats : nullptr;
+    RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
+    if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
+    RT_HIP(hipEventRecord(w.ev0, stream));
+    if (a.n_items > 0) {
+        RT_HIP(launch_render(sc->dev, a, sc->stack_need, counters, 0, stream));
+        if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
+    }
+    RT_HIP(hipEventRecord(w.ev1, stream));
+    w.pending = stats;
+    w.pending_counters = counters;
+}
+
+void finish(rt_scene *sc, hipStream_t stream) {
+    Workspace &w = workspace_for(sc, stream);
+    RT_HIP(hipStreamSynchronize(stream));
+    if (w.pending) {
+        rt_stats out;
+        std::memset(&out, 0, sizeof out);
+        if (w.pending_counters) {
+            StatsDev h;
+            RT_HIP(hipMemcpy(&h, w.stats, sizeof h, hipMemcpyDeviceToHost));
+            out.paths = h.paths; out.rays = h.rays; out.node_visits = h.node_visits;
+            for (int k = 0; k < RT_KIND_COUNT; k++) out.prim_tests[k] = h.prim_tests[k];
+            out.light_pdf_tests = h.light_pdf_tests; out.rng_draws = h.rng_draws;
+        }
+        float ms = 0.f;
+        RT_HIP(hipEventElapsedTime(&ms, w.ev0, w.ev1));
+        out.ms = (double)ms;
+        *w.pending = out;
+        w.pending = nullptr;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(desc && out, RT_ERR_INVALID, "rt_scene_create: null argument");
+        RT_REQUIRE(desc->abi_version == RT2022_ABI_VERSION, RT_ERR_INVALID, "rt_scene_create: abi_version mismatch");
+        Validator v(*desc);
+        v.check_pools();
+        v.check_ref(desc->root, "root");
+        int32_t need = 1, xdepth = 0;
+        v.need(desc->root, 0, need, xdepth);
+        RT_REQUIRE(need <= kStackLarge, RT_ERR_UNSUPPORTED, "scene needs a deeper traversal stack than the kernel provides");
+        RT_REQUIRE(xdepth <= RT_MAX_XFORM_DEPTH, RT_ERR_UNSUPPORTED, "movers nested deeper than RT_MAX_XFORM_DEPTH");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        RT_REQUIRE(e == hipSuccess && ndev > 0, RT_ERR_DEVICE, "rt_scene_create: no HIP device available (the path has no CPU fallback)");
+        rt_scene *sc = new rt_scene();
+        try {
+            RT_HIP(hipGetDevice(&sc->device));
+            SceneDev &s = sc->dev;
+            s.nodes = upload(desc->nodes, desc->n_nodes, sc->owned);
+            s.spheres = upload(desc->spheres, desc->n_spheres, sc->owned);
+            s.moving_spheres = upload(desc->moving_spheres, desc->n_moving_spheres, sc->owned);
+            s.rects = upload(desc->rects, desc->n_rects, sc->owned);
+            s.boxes = upload(desc->boxes, desc->n_boxes, sc->owned);
+            s.triangles = upload(desc->triangles, desc->n_triangles, sc->owned);
+            s.rings = upload(desc->rings, desc->n_rings, sc->owned);
+            s.media = upload(desc->media, desc->n_media, sc->owned);
+            s.xforms = upload(desc->xforms, desc->n_xforms, sc->owned);
+            s.lists = upload(desc->lists, desc->n_lists, sc->owned);
+            s.list_items = upload(desc->list_items, desc->n_list_items, sc->owned);
+            s.lights = upload(desc->lights, desc->n_lights, sc->owned);
+            s.materials = upload(desc->materials, desc->n_materials, sc->owned);
+            s.textures = upload(desc->textures, desc->n_textures, sc->owned);
+            s.images = upload(desc->images, desc->n_images, sc->owned);
+            s.image_data = upload(desc->image_data, desc->image_data_bytes, sc->owned);
+            s.perlins = upload(desc->perlins, desc->n_perlins, sc->owned);
+            s.root = desc->root;
+            s.n_lights = desc->n_lights;
+            sc->stack_need = (uint32_t)need;
+        } catch (...) {
+            for (void *p : sc->owned) (void)hipFree(p);
+            delete sc;
+            throw;
+        }
+        *out = sc;
+        return RT_OK;
+    });
+}
+
+int rt_scene_destroy(rt_scene *scene) {
+    return guarded([&]() -> int {
+        if (!scene) return RT_OK;
+        (void)hipDeviceSynchronize();
+        for (auto &kv : scene->ws) {
+            Workspace &w = kv.second;
+            if (w.work_counter) (void)hipFree(w.work_counter);
+            if (w.stats) (void)hipFree(w.stats);
+            if (w.partial) (void)hipFree(w.partial);
+            if (w.ev0) (void)hipEventDestroy(w.ev0);
+            if (w.ev1) (void)hipEventDestroy(w.ev1);
+        }
+        for (void *p : scene->owned) (void)hipFree(p);
+        delete scene;
+        return RT_OK;
+    });
+}
+
+int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
+                     double *d_out_rgb_sum, void *hip_stream, rt_stats *stats) {
+    return guarded([&]() -> int {
+        check_params(scene, cam, params);
+        RT_REQUIRE(d_out_rgb_sum || params->n_rows == 0, RT_ERR_INVALID, "rt_render_device: output is null");
+        enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, (hipStream_t)hip_stream, stats);
+        return RT_OK;
+    });
+}
+
+int rt_render_wait(rt_scene *scene, void *hip_stream) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene, RT_ERR_INVALID, "rt_render_wait: null scene");
+        finish(scene, (hipStream_t)hip_stream);
+        return RT_OK;
+    });
+}
+
+int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params, double *out_rgb_sum, rt_stats *stats) {
+    return guarded([&]() -> int {
+        check_params(scene, cam, params);
+        RT_REQUIRE(out_rgb_sum || params->n_rows == 0, RT_ERR_INVALID, "rt_render: output is null");
+        for (uint32_t i = 0; i < params->n_rows; i++)
+            RT_REQUIRE(params->row_ids[i] < (uint64_t)params->height * params->n_frames, RT_ERR_INVALID, "rt_render: row id out of range");
+        uint64_t n_values = (uint64_t)params->n_rows * params->width * 3;
+        uint32_t *d_rows = nullptr;
+        double *d_out = nullptr;
+        int rc = RT_OK;
+        try {
+            RT_HIP(hipMalloc((void **)&d_rows, (params->n_rows ? params->n_rows : 1) * sizeof(uint32_t)));
+            RT_HIP(hipMalloc((void **)&d_out, (n_values ? n_values : 1) * sizeof(double)));
+            if (params->n_rows) RT_HIP(hipMemcpy(d_rows, params->row_ids, params->n_rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+            // Poison the output so an unwritten pixel cannot pass for a result.
+            RT_HIP(hipMemset(d_out, 0xFF, (n_values ? n_values : 1) * sizeof(double)));
+            enqueue(scene, cam, params, d_rows, d_out, nullptr, stats);
+            finish(scene, nullptr);
+            if (n_values) RT_HIP(hipMemcpy(out_rgb_sum, d_out, n_values * sizeof(double), hipMemcpyDeviceToHost));
+        } catch (const Fail &e) {
+            set_error(e.msg);
+            rc = e.code;
+        }
+        if (d_rows) (void)hipFree(d_rows);
+        if (d_out) (void)hipFree(d_out);
+        return rc;
+    });
+}
+
+int rt_tonemap_device(const double *d_rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *d_rgb8, void *hip_stream) {
+    return guarded([&]() -> int {
+        RT_REQUIRE((d_rgb_sum && d_rgb8) || n_pixels == 0, RT_ERR_INVALID, "rt_tonemap_device: null argument");
+        if (n_pixels) RT_HIP(launch_tonemap(d_rgb_sum, n_pixels, spp, d_rgb8, (hipStream_t)hip_stream));
+        return RT_OK;
+    });
+}
+
+// ---- probes (include/rt2022_debug.h) --------------------------------------------------
+int rt_debug_math_device(int op, const double *a, const double *b, double *out, uint64_t n) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(a && out, RT_ERR_INVALID, "rt_debug_math_device: null argument");
+        double *da = nullptr, *db = nullptr, *dout = nullptr;
+        int rc = RT_OK;
+        try {
+            RT_HIP(hipMalloc((void **)&da, n * 8 + 8));
+            RT_HIP(hipMalloc((void **)&dout, n * 8 + 8));
+            RT_HIP(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+            if (b) { RT_HIP(hipMalloc((void **)&db, n * 8 + 8)); RT_HIP(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice)); }
+            RT_HIP(launch_math_probe(op, da, db, dout, n, nullptr));
+            RT_HIP(hipDeviceSynchronize());
+            RT_HIP(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+        } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
+        if (da) (void)hipFree(da);
+        if (db) (void)hipFree(db);
+        if (dout) (void)hipFree(dout);
+        return rc;
+    });
+}
+
+int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(out, RT_ERR_INVALID, "rt_debug_rng_device: null argument");
+        uint64_t *dout = nullptr;
+        int rc = RT_OK;
+        try {
+            RT_HIP(hipMalloc((void **)&dout, n * 8 + 8));
+            RT_HIP(launch_rng_probe(state, mode, lo, hi, bound, dout, n, nullptr));
+            RT_HIP(hipDeviceSynchronize());
+            RT_HIP(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+        } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
+        if (dout) (void)hipFree(dout);
+        return rc;
+    });
+}
+
+int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_scene_info: null scene");
+        if (stack_need) *stack_need = scene->stack_need;
+        if (grid_blocks) *grid_blocks = render_grid_blocks(scene->stack_need, false);
+        return RT_OK;
+    });
+}
+
+} // extern "C"

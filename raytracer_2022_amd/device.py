@@ -1,0 +1,54 @@
+"""Device side: a scene resident in HBM and the render calls (include/rt2022.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class DeviceScene:
+    """rt_scene: the flattened scene copied into HBM on the current HIP device."""
+
+    def __init__(self, desc):
+        self._h = C.c_void_p()
+        F.check(F.lib().rt_scene_create(C.byref(desc), C.byref(self._h)))
+
+    def info(self):
+        need, blocks = C.c_uint32(), C.c_int32()
+        F.check(F.lib().rt_debug_scene_info(self._h, C.byref(need), C.byref(blocks)))
+        return {"stack_need": need.value, "grid_blocks": blocks.value}
+
+    def render(self, cam, params, row_ids, want_stats=False):
+        """rt_render with host buffers → (n_rows, width, 3) float64 sums [, rt_stats]."""
+        rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
+        p = F.rt_params.from_buffer_copy(params)
+        p.n_rows = len(rows)
+        p.row_ids = rows.ctypes.data
+        if want_stats:
+            p.flags |= F.RT_FLAG_COUNTERS
+        out = np.empty((len(rows), p.width, 3), dtype=np.float64)
+        st = F.rt_stats()
+        F.check(F.lib().rt_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+        return (out, st) if want_stats else out
+
+    def render_device(self, cam, params, d_row_ids_ptr, n_rows, d_out_ptr, stream_ptr=None, stats=None):
+        """rt_render_device: device pointers in, enqueue on `stream_ptr` (hipStream_t as int)."""
+        p = F.rt_params.from_buffer_copy(params)
+        p.n_rows = n_rows
+        p.row_ids = d_row_ids_ptr
+        F.check(F.lib().rt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_out_ptr),
+                                         C.c_void_p(stream_ptr or 0), C.byref(stats) if stats is not None else None))
+
+    def wait(self, stream_ptr=None):
+        F.check(F.lib().rt_render_wait(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def close(self):
+        if self._h:
+            F.lib().rt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

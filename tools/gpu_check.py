@@ -1,0 +1,83 @@
+"""Quick GPU-vs-oracle parity + timing probe (development aid; the real tests live in tests/)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ctypes as C
+import raytracer_2022_amd as rt
+from raytracer_2022_amd import _ffi as F
+from oracle import oracle_ffi as O
+
+def math_parity():
+    rng = np.random.default_rng(1)
+    ok = True
+    for op, name, gen in [(0, 'sin', lambda: rng.uniform(-1e4, 1e4, 200000)), (1, 'cos', lambda: rng.uniform(-1e4, 1e4, 200000)),
+                          (0, 'sin_big', lambda: rng.uniform(-1e12, 1e12, 100000)),
+                          (2, 'acos', lambda: rng.uniform(-1, 1, 200000)), (4, 'log', lambda: rng.uniform(0, 1, 200000)),
+                          (5, 'sqrt', lambda: rng.uniform(0, 1e6, 400000)), ]:
+        a = gen()
+        out = np.empty_like(a)
+        F.check(F.lib().rt_debug_math_device(op, a.ctypes.data_as(C.POINTER(C.c_double)), None, out.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+        ref = O.math_array(op, a)
+        bad = (out.view(np.uint64) != ref.view(np.uint64)).sum()
+        print('math', name, 'mismatch', bad); ok &= bad == 0
+    a = rng.uniform(-2, 2, 200000); b = rng.uniform(-2, 2, 200000)
+    for op, name in [(3, 'atan2'), (6, 'div')]:
+        out = np.empty_like(a)
+        F.check(F.lib().rt_debug_math_device(op, a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+        ref = O.math_array(op, a, b)
+        bad = (out.view(np.uint64) != ref.view(np.uint64)).sum()
+        print('math', name, 'mismatch', bad); ok &= bad == 0
+    return ok
+
+def scene_parity(name, W, H, spp, chunk=0, param=0, depth=50):
+    s = rt.HostScene(name, seed=2022, param=param)
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, depth, bg, seed=2022, spp_chunk=chunk)
+    rows = rt.shuffled_rows(H, 7)
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=16, want_stats=True)
+    dev = rt.DeviceScene(s.desc)
+    t = time.time()
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    dt = time.time() - t
+    same_cnt = st.as_dict() == st_ref.as_dict()
+    nan_same = np.array_equal(np.isnan(out), np.isnan(ref))
+    m = ~np.isnan(ref)
+    rel = np.abs(out[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1e-300)
+    u8 = np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
+    bit = (out.view(np.uint64) != ref.view(np.uint64)).sum()
+    print(f'{name} {W}x{H}x{spp} chunk={chunk}: counters_equal={same_cnt} nan_same={nan_same} max_rel={rel.max() if rel.size else 0:.3e} u8_equal={u8} bit_mismatch={bit}/{out.size} gpu_wall={dt:.3f}s kernel_ms={st.ms:.2f} info={dev.info()}')
+    if not same_cnt:
+        print('  gpu', st.as_dict()); print('  ref', st_ref.as_dict())
+    return same_cnt and nan_same and u8 and (rel.max() if rel.size else 0) < 1e-9
+
+def timing(name, W, H, spp, chunk, param=0):
+    s = rt.HostScene(name, seed=2022, param=param)
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
+    rows = np.arange(H, dtype=np.uint32)
+    dev = rt.DeviceScene(s.desc)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    st2 = F.rt_stats()
+    p2 = F.rt_params.from_buffer_copy(p)
+    out2 = dev.render(cam, p2, rows)
+    # timed (no counters): use stats.ms of a non-counter run
+    pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
+    o = np.empty((len(rows), W, 3)); st3 = F.rt_stats()
+    F.check(F.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), o.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st3)))
+    print(f'TIMING {name} {W}x{H}x{spp} chunk={chunk}: rays={st.rays} kernel_ms={st3.ms:.2f} Mrays/s={st.rays / st3.ms / 1e3:.1f} nodes/ray={st.node_visits / st.rays:.1f} (counter-run ms={st.ms:.2f})')
+
+if __name__ == '__main__':
+    ok = math_parity()
+    ok &= scene_parity('cornell_box', 64, 64, 8)
+    ok &= scene_parity('random_scene', 96, 64, 4)
+    ok &= scene_parity('final_scene', 64, 64, 4)
+    ok &= scene_parity('final_scene', 64, 64, 8, chunk=3)
+    ok &= scene_parity('cornell_smoke', 48, 48, 4)
+    ok &= scene_parity('two_perlin_spheres', 48, 32, 4)
+    ok &= scene_parity('simple_light', 48, 32, 4)
+    ok &= scene_parity('earth', 48, 32, 4)
+    ok &= scene_parity('wwscene', 64, 36, 2)
+    print('ALL OK' if ok else 'SOME FAILED')
+    timing('final_scene', 400, 400, 16, 8)
+    timing('random_scene', 600, 400, 16, 8)
+    timing('cornell_box', 300, 300, 32, 8)
