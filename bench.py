@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the path-tracing hot loop on MI355X.
+
+One step = one pass of the hot path over one frame's worth of rows per GPU:
+the book-2 final scene at 800x800x1000 spp (BASELINE.json's metric config) with the
+scene, camera and row list already resident in HBM. At N GPUs the job is an
+N-frame film strip whose rows are dealt cyclically to the ranks (weak scaling,
+raytracer_2022_amd/film.py); the only exchange is the gather of the row buffers.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      algorithmic bytes / kernel time vs 8 TB/s HBM
+  cpu_baseline  the CPU oracle on a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+CONFIGS = {
+    # name: (scene, width, height, spp, description)
+    "c3": ("final_scene", 800, 800, 1000, "book-2 final scene 800x800x1000spp depth 50"),
+    "c2": ("random_scene", 1200, 800, 500, "book-1 final scene (random spheres) 1200x800x500spp depth 50"),
+    "c4": ("cornell_box", 600, 600, 1000, "book-3 Cornell box, MixturePdf, 600x600x1000spp depth 50"),
+}
+
+# Algorithmic bytes per unit, SURVEY.md §8(d).
+BYTES_NODE = 64
+BYTES_PRIM = {"sphere": 40, "moving_sphere": 80, "rect": 48, "box": 56, "triangle": 80, "ring": 32,
+              "medium": 24, "translate": 56, "rotate_y": 56, "zoom": 56, "list": 8, "node": 0}
+BYTES_RAY_STATE = 256      # 128 B read + 128 B write per ray segment
+BYTES_PIXEL = 24
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(st, n_pixels):
+    from raytracer_2022_amd import _ffi as F
+    prim = sum(BYTES_PRIM[F.KIND_NAMES[k]] * st["prim_tests"][k] for k in range(F.RT_KIND_COUNT))
+    traversal = BYTES_NODE * st["node_visits"] + prim
+    return {"traversal": traversal, "ray_state": BYTES_RAY_STATE * st["rays"], "pixels": BYTES_PIXEL * n_pixels,
+            "total": traversal + BYTES_RAY_STATE * st["rays"] + BYTES_PIXEL * n_pixels}
+
+
+def cpu_baseline(scene, cam, params, height, seed, target_s):
+    """Time the oracle (the reference's threading scheme) on a bounded sample of the same workload."""
+    from oracle import oracle_ffi as O
+    from raytracer_2022_amd import _ffi as F, shuffled_rows
+    cores = os.cpu_count() or 1
+    rows = shuffled_rows(height, seed)
+    p = F.rt_params.from_buffer_copy(params)
+    p.spp, p.spp_chunk, p.n_frames = 1, 0, 1
+    sub = rows[: max(cores, height // 8)]
+    t0 = time.time()
+    _, st = O.render_cpu(scene.desc, cam, p, sub, n_threads=cores, want_stats=True)
+    dt = max(time.time() - t0, 1e-3)
+    rate = st.rays / dt
+    # scale the sample (rows x spp) to ~target_s seconds of CPU work
+    want_rays = rate * target_s
+    rays_per_row_spp = st.rays / len(sub)
+    spp = int(max(1, min(params.spp, want_rays / (rays_per_row_spp * height))))
+    n_rows = int(max(cores, min(height, want_rays / (rays_per_row_spp * spp))))
+    p.spp = spp
+    sample_rows = rows[:n_rows]
+    t0 = time.time()
+    _, st = O.render_cpu(scene.desc, cam, p, sample_rows, n_threads=cores, want_stats=True)
+    dt = time.time() - t0
+    return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "%d shuffled rows x %d px x %d spp of the same scene/camera, %d threads in the reference's "
+                      "contiguous-section scheme (main.rs:109-116), %.1f s" % (n_rows, params.width, spp, cores, dt),
+            "rays": int(st.rays), "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (a reduced-spp run is NOT the headline number)")
+    ap.add_argument("--spp-chunk", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=2022)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--assets", default=os.path.join(HERE, "assets"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_2022_amd as rt
+    from raytracer_2022_amd import _ffi as F, film
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible — the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene_name, W, H, spp, desc_text = CONFIGS[args.config]
+    if args.spp > 0:
+        spp = args.spp
+    assets = args.assets if os.path.isdir(args.assets) else None
+    scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets)
+    cam, bg = scene.default_view(W / H)
+    params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=world, spp_chunk=args.spp_chunk)
+    dscene = rt.DeviceScene(scene.desc)
+
+    rows = film.rank_rows(H, world, args.seed, rank, world)
+    n_rows = len(rows)
+    d_rows = torch.from_numpy(rows.view(np.int32)).to(dev)
+    d_out = torch.empty((n_rows, W, 3), dtype=torch.float64, device=dev)
+    gather_list = [torch.empty_like(d_out) for _ in range(world)] if (world > 1 and rank == 0 and not args.no_gather) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(stats=None):
+        dscene.render_device(cam, params, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, stats)
+        if world > 1 and not args.no_gather:
+            dist.gather(d_out, gather_list, dst=0)
+
+    # Counter pass (untimed, deterministic): rays / node visits / primitive tests of one step.
+    pc = F.rt_params.from_buffer_copy(params)
+    pc.flags |= F.RT_FLAG_COUNTERS
+    st = F.rt_stats()
+    dscene.render_device(cam, pc, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, st)
+    dscene.wait(stream)
+    counts = st.as_dict()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = F.rt_stats()
+        step(s)
+        dscene.wait(stream)          # fills s.ms from the HIP events bracketing the launches on `stream`
+        kernel_ms.append(s.ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([counts["rays"], counts["paths"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rays, total_paths = float(cnt[0].item()), float(cnt[1].item())
+
+    if rank == 0:
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
+        value = total_rays * args.steps / elapsed / 1e6 if args.steps else 0.0
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        ab = algorithmic_bytes(counts, n_rows * W)
+        achieved = ab["total"] / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary+secondary), book-2 final scene 800x800x1000spp" if args.config == "c3" and args.spp == 0
+                      else "Mrays/s (primary+secondary)",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc_text if args.spp == 0 else desc_text + " [spp overridden to %d]" % spp,
+                       "scene": scene_name, "width": W, "height": H, "spp": spp, "max_depth": 50,
+                       "frames": world, "rows_per_gpu": n_rows, "spp_chunk": args.spp_chunk, "seed": args.seed,
+                       "sharding": "rows of an N-frame strip dealt cyclically; gather of row buffers to rank 0",
+                       "earth_texture": "assets/earthmap.ppm" if assets else "procedural stand-in"},
+            "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "pt_megakernel", "kernel_ms": round(k_ms, 3),
+                         "algorithmic_bytes_per_launch": int(ab["total"]),
+                         "traversal_only": {"bytes": int(ab["traversal"]),
+                                            "achieved": round(ab["traversal"] / (k_ms * 1e-3) / 1e9, 2),
+                                            "frac": round(ab["traversal"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         "note": "scene is L2-resident; ray state lives in registers — see DESIGN.md"},
+            "counters_rank0": counts,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                p1 = rt.make_params(W, H, spp, 50, bg, seed=args.seed)
+                out["cpu_baseline"] = cpu_baseline(scene, cam, p1, H, args.seed, args.cpu_seconds)
+            except Exception as e:  # the oracle is a checker, never the product: report and go on
+                out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

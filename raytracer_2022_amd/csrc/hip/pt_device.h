@@ -53,7 +53,33 @@ struct RenderArgs {
     const uint32_t *row_ids;           // device
     double *partial;                   // [n_chunks][n_pixels][3] (== out when n_chunks == 1)
     unsigned long long *work_counter;  // zeroed before launch
+    double *tape;                      // bounce records: max_depth * 4 doubles per launched lane
+    uint32_t node_quorum;              // lanes that must want a node step for the fast path (1..64)
     StatsDev *stats;                   // may be null
+};
+
+// ---- wavefront engine (pt_wavefront.hip) -------------------------------------------
+// A pool of path slots in HBM, structure-of-arrays ([field][slot]); workgroup b owns the
+// slots [b*kSlotsPerBlock, (b+1)*kSlotsPerBlock) for the whole frame.
+constexpr int kSlotsPerBlock = 4096;
+struct WfPool {
+    uint32_t n_slots;
+    uint32_t n_blocks;
+    uint8_t *kind;          // [P]    what the slot waits for (SlotKind)
+    double *ray;            // [7][P] ox oy oz dx dy dz tm  (world frame)
+    uint64_t *rng;          // [P]    path RNG state
+    double *hit_t;          // [P]
+    uint32_t *hit_leaf;     // [P]    winning leaf ref
+    uint32_t *hit_meta;     // [P]    box face | movers << 4
+    uint32_t *hit_chain;    // [4][P] enclosing movers (valid entries: movers)
+    uint64_t *item;         // [P]    pixel slot * n_chunks + chunk
+    uint32_t *smp;          // [P]    next sample of the item
+    uint32_t *smp_end;      // [P]
+    uint32_t *depth;        // [P]    remaining depth
+    uint32_t *pix;          // [3][P] px, py, frame of the item
+    double *pixel_sum;      // [3][P]
+    double *tape;           // [max_depth][4][P] bounce records
+    uint32_t *n_active;     // paths handed to the next trace pass (polled by the host)
 };
 
 // Traversal-stack capacities the megakernel is instantiated for.
@@ -64,6 +90,12 @@ constexpr int kBlock = 256;
 // Launchers (pt_kernel.hip). `stack_need` = entries the scene needs (host-computed).
 hipError_t launch_render(const SceneDev &scene, const RenderArgs &args, uint32_t stack_need, bool counters,
                          int n_blocks_hint, hipStream_t stream);
+// Wavefront engine: alternates shade / trace passes over the pool until it drains.
+// Blocks the calling thread (polls `n_active`). d_scene / d_args / d_pool are the
+// device-resident copies of the three structs.
+hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
+                                   const WfPool &pool, uint32_t stack_need, bool counters, uint32_t *h_active_pinned,
+                                   hipStream_t stream, uint32_t *out_iterations);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

@@ -1,0 +1,656 @@
+// pt_wavefront.hip — the wavefront engine: the same per-path algorithm as the megakernel
+// (pt_kernel.hip), cut at the one point where its register needs change character.
+//
+// Why two kernels: measured on MI355X, the single megakernel needs 256 VGPRs + scratch
+// (traversal state and the shading temporaries — Perlin turbulence, ONB, light pdfs — are
+// live together), which caps it at 2 waves/SIMD, and its spills land in the node loop
+// (profiles/r1_megakernel_*.txt). Split at "closest hit found", the traversal kernel is
+// lean and the shading kernel is wide, and each gets the occupancy it can use.
+//
+// Paths live in a pool of slots in HBM (WfPool, structure-of-arrays). Workgroup b owns
+// slots [b*4096, (b+1)*4096) for the whole frame, so there are no global queues and no
+// global atomics on the data path:
+//   wf_shade  counting-sorts its slots by what they wait for (miss / light / lambertian /
+//             metal / dielectric / isotropic / fresh) in LDS and shades them in that order —
+//             material dispatch by sorted type id, wave-uniform except at bin boundaries;
+//             finished paths are unwound from the bounce tape, added to their pixel, and
+//             replaced by the next sample / work item at once;
+//   wf_trace  compacts the slots that carry a ray into an LDS list and runs the in-wave
+//             scheduled traversal over it: lanes pull the next ray from the list as soon as
+//             theirs is done (__ballot / __popcll / __shfl refill), and the wave executes the
+//             operation most lanes wait for (node step, sphere test, box, medium, ...).
+// The host alternates the two until no slot carries a ray any more.
+//
+// Per-lane semantics never change: every path consumes its RNG stream and visits nodes
+// in the reference's order, so results stay bit-identical to the oracle.
+#include "pt_common.hpp"
+
+namespace rt2022 {
+
+namespace {
+
+enum SlotKind : uint32_t {
+    SK_IDLE = 0,        // nothing left to do
+    SK_FRESH = 1,       // no path yet: start the first sample
+    SK_TRACE = 2,       // carries a ray: world.hit pending
+    SK_MISS = 3,
+    SK_LIGHT = 4,
+    SK_LAMBERTIAN = 5,
+    SK_METAL = 6,
+    SK_DIELECTRIC = 7,
+    SK_ISOTROPIC = 8,
+    SK_COUNT = 9
+};
+
+constexpr int S = kSlotsPerBlock;
+
+struct PoolView {
+    const WfPool &p;
+    RT_DEV Ray load_ray(uint32_t slot) const {
+        const double *q = p.ray + slot;
+        uint64_t P = p.n_slots;
+        return Ray(Vec3(q[0], q[P], q[2 * P]), Vec3(q[3 * P], q[4 * P], q[5 * P]), q[6 * P]);
+    }
+    RT_DEV void store_ray(uint32_t slot, const Ray &r) const {
+        double *q = p.ray + slot;
+        uint64_t P = p.n_slots;
+        q[0] = r.orig.x; q[P] = r.orig.y; q[2 * P] = r.orig.z;
+        q[3 * P] = r.dir.x; q[4 * P] = r.dir.y; q[5 * P] = r.dir.z;
+        q[6 * P] = r.tm;
+    }
+};
+
+// Bounce tape of one slot (see Tape in pt_kernel.hip): record k, field f at tape[(k*4+f)*P + slot].
+struct SlotTape {
+    double *base;
+    uint64_t P;
+    uint32_t slot;
+    RT_DEV void put(uint32_t k, Vec3 w, double p) const {
+        double *q = base + ((uint64_t)k * 4) * P + slot;
+        q[0] = w.x; q[P] = w.y; q[2 * P] = w.z; q[3 * P] = p;
+    }
+    RT_DEV Vec3 unwind(uint32_t nb, Vec3 Lr) const {
+        for (uint32_t k = nb; k > 0; k--) {
+            const double *q = base + ((uint64_t)(k - 1) * 4) * P + slot;
+            Vec3 w(q[0], q[P], q[2 * P]);
+            double p = q[3 * P];
+            Lr = Vec3(0.0, 0.0, 0.0) + (w * Lr) / p;       // emitted + ((att*spdf) * L) / pdf_val, main.rs:267-271
+        }
+        return Lr;
+    }
+};
+
+RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
+    uint32_t idx = RT_REF_INDEX(leaf);
+    switch (RT_REF_KIND(leaf)) {
+        case RT_KIND_SPHERE: return s.spheres[idx].mat;
+        case RT_KIND_MOVING_SPHERE: return s.moving_spheres[idx].mat;
+        case RT_KIND_RECT: return s.rects[idx].mat;
+        case RT_KIND_BOX: return s.boxes[idx].mat;
+        case RT_KIND_TRIANGLE: return s.triangles[idx].mat;
+        case RT_KIND_RING: return s.rings[idx].mat;
+        default: return s.media[idx].mat;
+    }
+}
+
+} // namespace
+
+// =====================================================================================
+// Shade pass.
+// =====================================================================================
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock) wf_shade(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
+                                                   const WfPool *__restrict__ pp) {
+    __shared__ uint32_t hist[SK_COUNT];
+    __shared__ uint32_t cursor[SK_COUNT];
+    __shared__ uint32_t sorted[S];
+    __shared__ uint32_t n_sorted, n_traced;
+    const SceneDev &s = *sp;
+    const RenderArgs &a = *ap;
+    const WfPool &pool = *pp;
+    const PoolView pv{pool};
+    const uint32_t base = blockIdx.x * (uint32_t)S;
+    const uint32_t tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    Counters<STATS> cnt;
+
+    if (tid < SK_COUNT) hist[tid] = 0;
+    if (tid == 0) n_traced = 0;
+    __syncthreads();
+    // Counting sort of the block's slots by kind (idle slots and nothing else are dropped).
+    uint32_t my_kind[S / kBlock];
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++) {
+        uint32_t k = pool.kind[base + i * kBlock + tid];
+        my_kind[i] = k;
+        if (k != SK_IDLE) atomicAdd(&hist[k], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < SK_COUNT; k++) { cursor[k] = acc; acc += hist[k]; }
+        n_sorted = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++) {
+        uint32_t k = my_kind[i];
+        if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = (uint32_t)(i * kBlock) + tid;
+    }
+    __syncthreads();
+    const uint32_t total = n_sorted;
+    const Vec3 background = ld3(a.background);
+    uint32_t my_traced = 0;
+
+    for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
+        const uint32_t j = j0 + tid;
+        const bool on = j < total;
+        uint32_t slot = 0, kind = SK_IDLE;
+        if (on) { slot = base + sorted[j]; kind = pool.kind[slot]; }
+        bool alive = false;          // path continues with a new ray
+        bool ended = false;          // path ended: add to pixel, start the next sample
+        Ray r;
+        Rng rng;
+        uint32_t depth = 0;
+        Vec3 Lterm(0.0, 0.0, 0.0);
+        SlotTape tape{pool.tape, pool.n_slots, slot};
+
+        if (on && kind >= SK_MISS) {
+            r = pv.load_ray(slot);
+            rng = Rng(pool.rng[slot]);
+            depth = pool.depth[slot];
+            if (kind == SK_MISS) {
+                Lterm = background;                                   // main.rs:275-276
+                ended = true;
+            } else {
+                Winner w;
+                w.t = pool.hit_t[slot];
+                w.leaf = pool.hit_leaf[slot];
+                uint32_t meta = pool.hit_meta[slot];
+                w.face = meta & 0xFu;
+                w.chain.n = meta >> 4;
+                w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
+                if (w.chain.n > 0) {
+                    uint64_t P = pool.n_slots;
+                    w.chain.c0 = pool.hit_chain[slot];
+                    w.chain.c1 = pool.hit_chain[P + slot];
+                    w.chain.c2 = pool.hit_chain[2 * P + slot];
+                    w.chain.c3 = pool.hit_chain[3 * P + slot];
+                }
+                HitRec rec;
+                winner_record(s, r, w, rec);
+                const rt_material &mat = s.materials[rec.mat];
+                if (kind == SK_LIGHT) {                               // emitted; scatter = None (material/mod.rs:16-18,174-180)
+                    Lterm = rec.front_face ? texture_value(s, mat.tex, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);
+                    ended = true;
+                } else {
+                    Vec3 wgt;
+                    double p = 1.0;
+                    Vec3 dir;
+                    double tm = r.tm;
+                    if (kind == SK_LAMBERTIAN) {                      // material/mod.rs:51-65 + main.rs:263-271
+                        Vec3 att = texture_value(s, mat.tex, rec.u, rec.v, rec.p);
+                        rtm::Onb uvw = rtm::onb_from_w(rec.normal);
+                        double cosv;
+                        if (s.n_lights == 0) {                        // cosine-only mode
+                            dir = uvw.local_vec(random_cosine_direction(rng));
+                            cosv = rtm::dot(rtm::to_unit(dir), uvw.w);
+                            p = cosv <= 0.0 ? 0.0 : cosv / rtm::PI;
+                        } else {                                      // MixturePdf(lights, cos), pdf.rs:94-104
+                            if (rng.gen_range(0.0, 1.0) < 0.5) dir = lights_random(s, rec.p, rng);
+                            else dir = uvw.local_vec(random_cosine_direction(rng));
+                            double lp = lights_pdf_value<STATS>(s, rec.p, dir, cnt);
+                            cosv = rtm::dot(rtm::to_unit(dir), uvw.w);
+                            double cp = cosv <= 0.0 ? 0.0 : cosv / rtm::PI;
+                            p = 0.5 * lp + 0.5 * cp;
+                        }
+                        double cosine = rtm::dot(rec.normal, rtm::to_unit(dir));
+                        double spdf = cosine < 0.0 ? 0.0 : cosine / rtm::PI;
+                        wgt = att * spdf;
+                    } else if (kind == SK_METAL) {                    // material/mod.rs:85-96
+                        Vec3 reflected = rtm::reflect(rtm::to_unit(r.dir), rec.normal);
+                        dir = reflected + random_in_unit_sphere(rng) * mat.param;
+                        wgt = ld3(mat.albedo);
+                        tm = 0.0;                                     // time = 0., mod.rs:91
+                    } else if (kind == SK_DIELECTRIC) {               // material/mod.rs:120-147
+                        double refraction_ratio = rec.front_face ? 1.0 / mat.param : mat.param;
+                        Vec3 unit_direction = rtm::to_unit(r.dir);
+                        double cos_theta = rtm::fmin_(rtm::dot(-unit_direction, rec.normal), 1.0);
+                        double sin_theta = rtm::sqrt_(1.0 - cos_theta * cos_theta);
+                        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+                        double random_double = rng.gen_range(0.0, 1.0);
+                        dir = (cannot_refract || reflectance(cos_theta, refraction_ratio) > random_double)
+                                  ? rtm::reflect(unit_direction, rec.normal)
+                                  : rtm::refract(unit_direction, rec.normal, refraction_ratio);
+                        wgt = Vec3(1.0, 1.0, 1.0);
+                    } else {                                          // Isotropic, material/mod.rs:207-213
+                        wgt = texture_value(s, mat.tex, rec.u, rec.v, rec.p);
+                        dir = random_in_unit_sphere(rng);
+                    }
+                    uint32_t nb = a.max_depth - depth;
+                    tape.put(nb, wgt, p);
+                    r = Ray(rec.p, dir, tm);
+                    depth--;
+                    if (depth == 0) ended = true;                     // the next ray_color returns (0,0,0), main.rs:240-242
+                    else alive = true;
+                }
+            }
+            if (ended) {
+                uint32_t nb = a.max_depth - depth;
+                Vec3 Lp = tape.unwind(nb, Lterm);
+                uint64_t P = pool.n_slots;
+                double *ps = pool.pixel_sum + slot;
+                ps[0] = ps[0] + Lp.x; ps[P] = ps[P] + Lp.y; ps[2 * P] = ps[2 * P] + Lp.z;   // pixel_color += ..., main.rs:150
+            }
+            cnt.draws(rng.draws);                                     // words drawn while scattering
+            rng.draws = 0;
+        }
+
+        // Next sample of the item, or the next item (main.rs:140-152).
+        bool want_path = on && (kind == SK_FRESH || ended);
+        if (want_path) {
+            uint64_t P = pool.n_slots;
+            uint32_t smp = 0, smp_end = 0;
+            bool have_item = kind != SK_FRESH;
+            if (have_item) { smp = pool.smp[slot]; smp_end = pool.smp_end[slot]; }
+            for (int guard = 0; guard < 1 << 20; guard++) {           // loops only through degenerate items (spp or depth 0)
+                bool need = !have_item || smp == smp_end;
+                if (need && have_item) {                              // section_pixel_color.push(pixel_color), main.rs:152
+                    uint64_t item = pool.item[slot];
+                    uint64_t pix_slot = item / a.n_chunks;
+                    uint32_t chunk_id = (uint32_t)(item - pix_slot * a.n_chunks);
+                    double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
+                    const double *ps = pool.pixel_sum + slot;
+                    o[0] = ps[0]; o[1] = ps[P]; o[2] = ps[2 * P];
+                    have_item = false;
+                }
+                unsigned long long m = __ballot(need);
+                if (m) {
+                    int leader = __ffsll((long long)m) - 1;
+                    unsigned long long wbase = 0;
+                    if ((int)lane == leader) wbase = atomicAdd(a.work_counter, (unsigned long long)__popcll(m));
+                    wbase = __shfl(wbase, leader);
+                    if (need) {
+                        unsigned long long item = wbase + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                        if (item < a.n_items) {
+                            uint64_t pix_slot = item / a.n_chunks;
+                            uint32_t chunk_id = (uint32_t)(item - pix_slot * a.n_chunks);
+                            uint64_t yi = pix_slot / a.width;
+                            uint32_t px = (uint32_t)(pix_slot - yi * a.width);
+                            uint32_t g = a.row_ids[yi];
+                            uint32_t frame = g / a.height;
+                            uint32_t py = g - frame * a.height;
+                            smp = chunk_id * a.chunk;
+                            smp_end = smp + a.chunk < a.spp ? smp + a.chunk : a.spp;
+                            pool.item[slot] = item;
+                            pool.pix[slot] = px; pool.pix[P + slot] = py; pool.pix[2 * P + slot] = frame;
+                            double *ps = pool.pixel_sum + slot;
+                            ps[0] = 0.0; ps[P] = 0.0; ps[2 * P] = 0.0;
+                            have_item = true;
+                        }
+                    }
+                }
+                if (!have_item) break;                                // no work left: the slot goes idle
+                if (smp == smp_end) continue;                         // empty chunk (spp == 0): store zeros next turn
+                uint32_t px = pool.pix[slot], py = pool.pix[P + slot], frame = pool.pix[2 * P + slot];
+                uint64_t pixel = (uint64_t)py * a.width + px;
+                rng = Rng(rtm::path_key(a.seed, frame, pixel, smp));  // main.rs:144-149
+                double rand_u = rng.gen_f64();
+                double rand_v = rng.gen_f64();
+                double u = ((double)px + rand_u) / (double)(a.width - 1);
+                double v = ((double)py + rand_v) / (double)(a.height - 1);
+                r = get_ray(a.cam, u, v, rng);
+                depth = a.max_depth;
+                smp++;
+                cnt.path();
+                cnt.draws(rng.draws);                                 // words drawn while aiming the camera ray
+                rng.draws = 0;
+                if (depth == 0) continue;                             // MAX_DEPTH == 0: black at once
+                alive = true;
+                break;
+            }
+            pool.smp[slot] = smp;
+            pool.smp_end[slot] = smp_end;
+        }
+
+        if (on) {
+            if (alive) {
+                cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
+                pv.store_ray(slot, r);
+                pool.rng[slot] = rng.s;
+                pool.depth[slot] = depth;
+                pool.kind[slot] = (uint8_t)SK_TRACE;
+                my_traced++;
+            } else {
+                pool.kind[slot] = (uint8_t)SK_IDLE;
+            }
+        }
+    }
+    // Paths handed to the trace pass (the host stops when the whole pool reports none).
+    if (my_traced) atomicAdd(&n_traced, my_traced);
+    __syncthreads();
+    if (tid == 0 && n_traced) atomicAdd(pool.n_active, n_traced);
+    if (STATS) cnt.flush(a.stats);
+}
+
+// =====================================================================================
+// Trace pass: closest hit of every pending ray, in-wave scheduled.
+// =====================================================================================
+namespace {
+
+struct TLane {
+    XRay cur;              // ray inside the enclosing movers
+    Vec3 inv;              // 1 / cur.d   (aabb.rs:19, hoisted: same value at every node)
+    double a_len;          // cur.d.length_sqr()  (sphere.rs:41, hoisted likewise)
+    double tm;
+    double closest;
+    Rng rng;
+    Chain ctx;
+    Chain win_chain;
+    uint32_t win_leaf, win_face;
+    uint32_t slot;
+    int sp;
+    uint32_t top, op;
+    bool has_ray;
+};
+
+template <int STACK>
+struct TStack {
+    uint32_t *col;
+    RT_DEV void push(TLane &L, uint32_t ref) { if (L.sp < STACK) { col[L.sp * kBlock] = ref; L.sp++; } }
+    RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * kBlock]; } return REF_EMPTY; }
+};
+
+RT_DEV void t_set_cur(TLane &L, const XRay &c) {
+    L.cur = c;
+    L.inv = Vec3(1.0 / c.d.x, 1.0 / c.d.y, 1.0 / c.d.z);
+    L.a_len = c.d.length_sqr();
+}
+RT_DEV void t_accept(TLane &L, double t, uint32_t face) {
+    L.closest = t;
+    L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx;
+}
+template <int STACK>
+RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
+    L.top = st.pop(L);
+    L.op = classify(L.top);
+}
+
+} // namespace
+
+template <int STACK, bool STATS>
+__global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
+                                                   const WfPool *__restrict__ pp) {
+    __shared__ uint32_t stack_lds[STACK * kBlock];
+    __shared__ uint16_t list[S];
+    __shared__ uint32_t list_n, list_next;
+    const SceneDev &s = *sp;
+    const RenderArgs &a = *ap;
+    const WfPool &pool = *pp;
+    const PoolView pv{pool};
+    const uint32_t base = blockIdx.x * (uint32_t)S;
+    const uint32_t tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    Counters<STATS> cnt;
+    TStack<STACK> st{stack_lds + tid};
+
+    if (tid == 0) { list_n = 0; list_next = 0; }
+    __syncthreads();
+    // Compact the slots that carry a ray (wave-level: one LDS atomic per wave and pass).
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++) {
+        uint32_t local = (uint32_t)(i * kBlock) + tid;
+        bool pending = pool.kind[base + local] == SK_TRACE;
+        unsigned long long m = __ballot(pending);
+        if (m) {
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t wbase = 0;
+            if ((int)lane == leader) wbase = atomicAdd(&list_n, (uint32_t)__popcll(m));
+            wbase = __shfl(wbase, leader);
+            if (pending) list[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)local;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_list = list_n;
+    if (n_list == 0) return;
+
+    TLane L;
+    L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0;
+    L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
+    L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
+    L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
+    const double t_min = a.t_min;
+    const int node_quorum = (int)a.node_quorum;
+
+    for (;;) {
+        // Fast path: keep stepping nodes while enough lanes want to.
+        for (;;) {
+            bool isn = L.op == OP_NODE;
+            int nn = __popcll(__ballot(isn));
+            if (nn < node_quorum) break;
+            if (isn) {
+                // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
+                // at once, the right one waits on the stack and is tested against the then-closest hit.
+                cnt.node();
+                const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + RT_REF_INDEX(L.top));
+                uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                double bmin[3] = {rtm::u2d(((uint64_t)q0.y << 32) | q0.x), rtm::u2d(((uint64_t)q0.w << 32) | q0.z), rtm::u2d(((uint64_t)q1.y << 32) | q1.x)};
+                double bmax[3] = {rtm::u2d(((uint64_t)q1.w << 32) | q1.z), rtm::u2d(((uint64_t)q2.y << 32) | q2.x), rtm::u2d(((uint64_t)q2.w << 32) | q2.z)};
+                uint32_t left = q3.x, right = q3.y;
+                double tmn = t_min, tmx = L.closest;
+                bool miss = false;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double inv_d = L.inv[i];
+                    double t0 = (bmin[i] - L.cur.o[i]) * inv_d;
+                    double t1 = (bmax[i] - L.cur.o[i]) * inv_d;
+                    if (inv_d < 0.0) { double tmp = t0; t0 = t1; t1 = tmp; }
+                    tmn = t0 > tmn ? t0 : tmn;
+                    tmx = t1 < tmx ? t1 : tmx;
+                    miss = miss || (tmx <= tmn);
+                }
+                if (!miss) {
+                    st.push(L, right);
+                    L.top = left;
+                } else {
+                    L.top = st.pop(L);
+                }
+                L.op = classify(L.top);
+            }
+        }
+        // Vote: the label most lanes are waiting on (ties -> lowest id).
+        int best = -1, best_n = 0;
+#pragma unroll
+        for (int o = 0; o < (int)OP_COUNT; o++) {
+            int n = __popcll(__ballot(L.op == (uint32_t)o));
+            if (n > best_n) { best_n = n; best = o; }
+        }
+        if (best < 0) break;                                          // every lane idle
+        if (L.op != (uint32_t)best) {
+            // parked: this lane's operation did not win the vote
+        } else if (best == OP_NODE) {
+            cnt.node();
+            const rt_bvh_node &n = s.nodes[RT_REF_INDEX(L.top)];
+            double tmn = t_min, tmx = L.closest;
+            bool miss = false;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double inv_d = L.inv[i];
+                double t0 = (n.bmin[i] - L.cur.o[i]) * inv_d;
+                double t1 = (n.bmax[i] - L.cur.o[i]) * inv_d;
+                if (inv_d < 0.0) { double tmp = t0; t0 = t1; t1 = tmp; }
+                tmn = t0 > tmn ? t0 : tmn;
+                tmx = t1 < tmx ? t1 : tmx;
+                miss = miss || (tmx <= tmn);
+            }
+            if (!miss) { st.push(L, n.right); L.top = n.left; L.op = classify(L.top); }
+            else t_next(L, st);
+        } else if (best == OP_SPHERE) {                               // Sphere / MovingSphere::hit
+            uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
+            cnt.prim(kind);
+            Vec3 center;
+            double radius;
+            if (kind == RT_KIND_SPHERE) { const rt_sphere &q = s.spheres[idx]; center = ld3(q.center); radius = q.radius; }
+            else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
+            double t;
+            if (sphere_t(center, radius, L.cur, L.a_len, t_min, L.closest, t)) t_accept(L, t, 0);
+            t_next(L, st);
+        } else if (best == OP_RECT) {
+            cnt.prim(RT_KIND_RECT);
+            const rt_rect &q = s.rects[RT_REF_INDEX(L.top)];
+            double t;
+            if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, L.cur, t_min, L.closest, t)) t_accept(L, t, 0);
+            t_next(L, st);
+        } else if (best == OP_BOX) {
+            cnt.prim(RT_KIND_BOX);
+            double t;
+            uint32_t face = 0;
+            if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, t_min, L.closest, t, face)) t_accept(L, t, face);
+            t_next(L, st);
+        } else if (best == OP_MEDIUM) {                               // ConstantMedium::hit, constantmedium.rs:49-83
+            cnt.prim(RT_KIND_MEDIUM);
+            const rt_medium &m = s.media[RT_REF_INDEX(L.top)];
+            double t1, t2;
+            if (boundary_t<STATS>(s, m.boundary, L.cur, L.tm, -rtm::INF, rtm::INF, t1, cnt) &&
+                boundary_t<STATS>(s, m.boundary, L.cur, L.tm, t1 + 0.0001, rtm::INF, t2, cnt)) {
+                t1 = rtm::fmax_(t1, t_min);
+                t2 = rtm::fmin_(t2, L.closest);
+                if (!(t1 >= t2)) {
+                    t1 = rtm::fmax_(t1, 0.0);
+                    double ray_length = L.cur.d.length();
+                    double distance_inside_boundary = (t2 - t1) * ray_length;
+                    double rnd = L.rng.gen_f64();
+                    double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
+                    if (!(hit_distance > distance_inside_boundary)) t_accept(L, t1 + hit_distance / ray_length, 0);
+                }
+            }
+            t_next(L, st);
+        } else if (best == OP_MISC) {                                 // Triangle, Ring
+            uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
+            cnt.prim(kind);
+            double t;
+            bool h = kind == RT_KIND_TRIANGLE ? triangle_t(s.triangles[idx], L.cur, t_min, L.closest, t)
+                                              : ring_t(s.rings[idx], L.cur, t_min, L.closest, t);
+            if (h) t_accept(L, t, 0);
+            t_next(L, st);
+        } else if (best == OP_CTX) {                                  // movers in / out, HittableList expansion
+            if (L.top == REF_POPCTX) {
+                L.ctx.n--;
+                Ray wr = pv.load_ray(L.slot);
+                t_set_cur(L, ray_at_level(s, L.ctx, L.ctx.n, XRay{wr.orig, wr.dir}));
+                t_next(L, st);
+            } else {
+                uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
+                cnt.prim(kind);
+                if (kind == RT_KIND_LIST) {
+                    const rt_list &l = s.lists[idx];
+                    for (uint32_t i = l.count; i > 0; i--) st.push(L, s.list_items[l.first + i - 1]);
+                    t_next(L, st);
+                } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
+                    L.ctx.push(L.top);
+                    t_set_cur(L, xform_ray(s, L.top, L.cur));
+                    st.push(L, REF_POPCTX);
+                    L.top = s.xforms[idx].child;
+                    L.op = classify(L.top);
+                } else {
+                    t_next(L, st);
+                }
+            }
+        } else {
+            // OP_SHADE here = "this lane's traversal is finished (or it has no ray yet)":
+            // publish the winner, then pull the next ray from the block's list.
+            if (L.has_ray) {
+                uint32_t slot = L.slot;
+                bool found = L.win_leaf != REF_EMPTY;
+                uint32_t kind = SK_MISS;
+                if (found) {
+                    uint64_t P = pool.n_slots;
+                    pool.hit_t[slot] = L.closest;
+                    pool.hit_leaf[slot] = L.win_leaf;
+                    pool.hit_meta[slot] = L.win_face | (L.win_chain.n << 4);
+                    if (L.win_chain.n > 0) {
+                        pool.hit_chain[slot] = L.win_chain.c0;
+                        pool.hit_chain[P + slot] = L.win_chain.c1;
+                        pool.hit_chain[2 * P + slot] = L.win_chain.c2;
+                        pool.hit_chain[3 * P + slot] = L.win_chain.c3;
+                    }
+                    uint32_t mk = s.materials[leaf_material(s, L.win_leaf)].kind;
+                    kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_LAMBERTIAN ? SK_LAMBERTIAN
+                         : mk == RT_MAT_METAL ? SK_METAL : mk == RT_MAT_DIELECTRIC ? SK_DIELECTRIC : SK_ISOTROPIC;
+                }
+                pool.kind[slot] = (uint8_t)kind;
+                if (L.rng.draws) { pool.rng[slot] = L.rng.s; cnt.draws(L.rng.draws); }
+                L.has_ray = false;
+            }
+            unsigned long long m = __ballot(true);
+            int leader = __ffsll((long long)m) - 1;
+            uint32_t wbase = 0;
+            if ((int)lane == leader) wbase = atomicAdd(&list_next, (uint32_t)__popcll(m));
+            wbase = __shfl(wbase, leader);
+            uint32_t mine = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (mine < n_list) {
+                L.slot = base + list[mine];
+                Ray wr = pv.load_ray(L.slot);
+                L.tm = wr.tm;
+                L.rng = Rng(pool.rng[L.slot]);
+                t_set_cur(L, XRay{wr.orig, wr.dir});
+                L.closest = rtm::F64_MAX;
+                L.win_leaf = REF_EMPTY; L.win_face = 0;
+                L.ctx.n = 0;
+                L.sp = 0;
+                L.top = s.root;
+                L.op = classify(L.top);
+                L.has_ray = true;
+            } else {
+                L.op = OP_IDLE;
+            }
+        }
+    }
+    if (STATS) cnt.flush(a.stats);
+}
+
+// ---- host side of the engine -------------------------------------------------------------
+template <bool STATS>
+static void launch_shade(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((wf_shade<STATS>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+}
+template <int STACK, bool STATS>
+static void launch_trace(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((wf_trace<STACK, STATS>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+}
+
+hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
+                                   const WfPool &pool, uint32_t stack_need, bool counters, uint32_t *h_active_pinned,
+                                   hipStream_t stream, uint32_t *out_iterations) {
+    if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
+    const uint32_t blocks = pool.n_blocks;
+    hipError_t e;
+    // Every slot starts FRESH.
+    if ((e = hipMemsetAsync(pool.kind, SK_FRESH, pool.n_slots, stream)) != hipSuccess) return e;
+    uint32_t iterations = 0;
+    const int poll_every = 4;
+    for (;;) {
+        for (int k = 0; k < poll_every; k++) {
+            if ((e = hipMemsetAsync(pool.n_active, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+            if (counters) launch_shade<true>(d_scene, d_args, d_pool, blocks, stream);
+            else launch_shade<false>(d_scene, d_args, d_pool, blocks, stream);
+            if (stack_need <= (uint32_t)kStackSmall) {
+                if (counters) launch_trace<kStackSmall, true>(d_scene, d_args, d_pool, blocks, stream);
+                else launch_trace<kStackSmall, false>(d_scene, d_args, d_pool, blocks, stream);
+            } else {
+                if (counters) launch_trace<kStackLarge, true>(d_scene, d_args, d_pool, blocks, stream);
+                else launch_trace<kStackLarge, false>(d_scene, d_args, d_pool, blocks, stream);
+            }
+            iterations++;
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_active_pinned, pool.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        if (*h_active_pinned == 0) break;       // the last shade pass handed no ray on: the pool has drained
+        if (iterations > (1u << 26)) return hipErrorUnknown;
+    }
+    if (out_iterations) *out_iterations = iterations;
+    return hipSuccess;
+}
+
+} // namespace rt2022

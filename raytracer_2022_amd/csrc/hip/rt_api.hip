@@ -198,6 +198,17 @@ struct Workspace {
     StatsDev *stats = nullptr;
     double *partial = nullptr;
     uint64_t partial_bytes = 0;
+    double *tape = nullptr;
+    uint64_t tape_bytes = 0;
+    // wavefront engine
+    WfPool pool{};
+    std::vector<void *> pool_owned;
+    uint32_t pool_slots = 0, pool_depth = 0;
+    SceneDev *d_scene = nullptr;
+    RenderArgs *d_args = nullptr;
+    WfPool *d_pool = nullptr;
+    uint32_t *h_active = nullptr;     // pinned
+    uint32_t iterations = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt_stats *pending = nullptr;      // host stats to fill at rt_render_wait
     bool pending_counters = false;
@@ -209,6 +220,9 @@ struct rt_scene {
     SceneDev dev{};
     std::vector<void *> owned;
     uint32_t stack_need = 1;
+    uint32_t node_quorum = 24;
+    int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
+    int max_pool_blocks = 0;          // 0 = 4 x CUs
     int device = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
@@ -234,6 +248,55 @@ void check_params(const rt_scene *scene, const rt_camera *cam, const rt_params *
     RT_REQUIRE(cam->time0 < cam->time1, RT_ERR_INVALID, "camera time0 >= time1 (gen_range panics in the reference, camera.rs:71)");
     RT_REQUIRE(p->n_rows == 0 || p->row_ids, RT_ERR_INVALID, "row_ids is null");
     RT_REQUIRE((uint64_t)p->height * p->n_frames <= 0xFFFFFFFFull, RT_ERR_INVALID, "height * n_frames overflows a row id");
+}
+
+template <class T>
+T *pool_alloc(Workspace &w, uint64_t count) {
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    w.pool_owned.push_back(p);
+    return (T *)p;
+}
+
+// (Re)allocate the wavefront pool for `blocks` workgroups and `depth` tape records.
+void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stream) {
+    uint32_t slots = blocks * (uint32_t)kSlotsPerBlock;
+    if (depth == 0) depth = 1;
+    if (w.d_scene == nullptr) {
+        RT_HIP(hipMalloc((void **)&w.d_scene, sizeof(SceneDev)));
+        RT_HIP(hipMalloc((void **)&w.d_args, sizeof(RenderArgs)));
+        RT_HIP(hipMalloc((void **)&w.d_pool, sizeof(WfPool)));
+        RT_HIP(hipHostMalloc((void **)&w.h_active, sizeof(uint32_t)));
+    }
+    if (slots <= w.pool_slots && depth <= w.pool_depth) { w.pool.n_blocks = blocks; w.pool.n_slots = w.pool_slots; return; }
+    RT_HIP(hipStreamSynchronize(stream));
+    for (void *p : w.pool_owned) RT_HIP(hipFree(p));
+    w.pool_owned.clear();
+    w.pool_slots = 0; w.pool_depth = 0;
+    if (slots < w.pool.n_slots) slots = w.pool.n_slots;
+    uint64_t tape_bytes = (uint64_t)slots * depth * 4 * sizeof(double);
+    RT_REQUIRE(tape_bytes <= (64ull << 30), RT_ERR_UNSUPPORTED, "max_depth too large for the bounce tape");
+    uint64_t P = slots;
+    WfPool &q = w.pool;
+    q.n_slots = slots;
+    q.n_blocks = blocks;
+    q.kind = pool_alloc<uint8_t>(w, P);
+    q.ray = pool_alloc<double>(w, 7 * P);
+    q.rng = pool_alloc<uint64_t>(w, P);
+    q.hit_t = pool_alloc<double>(w, P);
+    q.hit_leaf = pool_alloc<uint32_t>(w, P);
+    q.hit_meta = pool_alloc<uint32_t>(w, P);
+    q.hit_chain = pool_alloc<uint32_t>(w, 4 * P);
+    q.item = pool_alloc<uint64_t>(w, P);
+    q.smp = pool_alloc<uint32_t>(w, P);
+    q.smp_end = pool_alloc<uint32_t>(w, P);
+    q.depth = pool_alloc<uint32_t>(w, P);
+    q.pix = pool_alloc<uint32_t>(w, 3 * P);
+    q.pixel_sum = pool_alloc<double>(w, 3 * P);
+    q.tape = pool_alloc<double>(w, (uint64_t)depth * 4 * P);
+    q.n_active = pool_alloc<uint32_t>(w, 1);
+    w.pool_slots = slots;
+    w.pool_depth = depth;
 }
 
 // Enqueue one render on `stream`; row ids and output are device pointers.
@@ -268,13 +331,53 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     } else {
         a.partial = d_out;
     }
+    a.node_quorum = sc->node_quorum;
     a.work_counter = w.work_counter;
     a.stats = counters ? w.stats : nullptr;
+    if (sc->engine == 1) {
+        // Wavefront engine: pool of path slots, shade / trace passes until it drains.
+        hipDeviceProp_t prop;
+        RT_HIP(hipGetDeviceProperties(&prop, sc->device));
+        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 4u * (uint32_t)prop.multiProcessorCount;
+        uint64_t want = (a.n_items + kSlotsPerBlock - 1) / kSlotsPerBlock;
+        uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+        ensure_pool(w, blocks, p->max_depth, stream);
+        a.tape = nullptr;
+        RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
+        if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
+        RT_HIP(hipMemcpyAsync(w.d_scene, &sc->dev, sizeof(SceneDev), hipMemcpyHostToDevice, stream));
+        RT_HIP(hipMemcpyAsync(w.d_args, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+        RT_HIP(hipMemcpyAsync(w.d_pool, &w.pool, sizeof(WfPool), hipMemcpyHostToDevice, stream));
+        RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
+        RT_HIP(hipEventRecord(w.ev0, stream));
+        if (a.n_items > 0) {
+            RT_HIP(launch_render_wavefront(w.d_scene, w.d_args, w.d_pool, w.pool, sc->stack_need, counters, w.h_active, stream, &w.iterations));
+            if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
+        }
+        RT_HIP(hipEventRecord(w.ev1, stream));
+        w.pending = stats;
+        w.pending_counters = counters;
+        return;
+    }
+    // Megakernel engine. Bounce tape: max_depth records of 4 doubles for every lane of the persistent grid.
+    int blocks = render_grid_blocks(sc->stack_need, counters);
+    uint64_t want_blocks = (a.n_items + kBlock - 1) / kBlock;
+    if ((uint64_t)blocks > want_blocks) blocks = (int)(want_blocks ? want_blocks : 1);
+    uint64_t tape_bytes = (uint64_t)blocks * kBlock * (uint64_t)(p->max_depth ? p->max_depth : 1) * 4 * sizeof(double);
+    RT_REQUIRE(tape_bytes <= (32ull << 30), RT_ERR_UNSUPPORTED, "max_depth too large for the bounce tape");
+    if (tape_bytes > w.tape_bytes) {
+        RT_HIP(hipStreamSynchronize(stream));
+        if (w.tape) RT_HIP(hipFree(w.tape));
+        w.tape = nullptr; w.tape_bytes = 0;
+        RT_HIP(hipMalloc((void **)&w.tape, tape_bytes));
+        w.tape_bytes = tape_bytes;
+    }
+    a.tape = w.tape;
     RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
     if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
     RT_HIP(hipEventRecord(w.ev0, stream));
     if (a.n_items > 0) {
-        RT_HIP(launch_render(sc->dev, a, sc->stack_need, counters, 0, stream));
+        RT_HIP(launch_render(sc->dev, a, sc->stack_need, counters, blocks, stream));
         if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
     }
     RT_HIP(hipEventRecord(w.ev1, stream));
@@ -364,6 +467,12 @@ int rt_scene_destroy(rt_scene *scene) {
             if (w.work_counter) (void)hipFree(w.work_counter);
             if (w.stats) (void)hipFree(w.stats);
             if (w.partial) (void)hipFree(w.partial);
+            if (w.tape) (void)hipFree(w.tape);
+            for (void *p : w.pool_owned) (void)hipFree(p);
+            if (w.d_scene) (void)hipFree(w.d_scene);
+            if (w.d_args) (void)hipFree(w.d_args);
+            if (w.d_pool) (void)hipFree(w.d_pool);
+            if (w.h_active) (void)hipHostFree(w.h_active);
             if (w.ev0) (void)hipEventDestroy(w.ev0);
             if (w.ev1) (void)hipEventDestroy(w.ev1);
         }
@@ -463,6 +572,26 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
         } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
         if (dout) (void)hipFree(dout);
         return rc;
+    });
+}
+
+int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
+        RT_REQUIRE(node_quorum >= 1 && node_quorum <= 64, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64");
+        scene->node_quorum = node_quorum;
+        return RT_OK;
+    });
+}
+
+int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_engine: null scene");
+        RT_REQUIRE(engine == 0 || engine == 1, RT_ERR_INVALID, "rt_debug_set_engine: engine must be 0 (megakernel) or 1 (wavefront)");
+        RT_REQUIRE(max_pool_blocks >= 0 && max_pool_blocks <= 65535, RT_ERR_INVALID, "rt_debug_set_engine: bad max_pool_blocks");
+        scene->engine = engine;
+        scene->max_pool_blocks = max_pool_blocks;
+        return RT_OK;
     });
 }
 

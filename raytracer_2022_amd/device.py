@@ -18,6 +18,13 @@ class DeviceScene:
         F.check(F.lib().rt_debug_scene_info(self._h, C.byref(need), C.byref(blocks)))
         return {"stack_need": need.value, "grid_blocks": blocks.value}
 
+    def set_tuning(self, node_quorum):
+        F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum))
+
+    def set_engine(self, engine, max_pool_blocks=0):
+        """engine: "wavefront" (default) or "mega"."""
+        F.check(F.lib().rt_debug_set_engine(self._h, {"mega": 0, "wavefront": 1}[engine], max_pool_blocks))
+
     def render(self, cam, params, row_ids, want_stats=False):
         """rt_render with host buffers → (n_rows, width, 3) float64 sums [, rt_stats]."""
         rows = np.ascontiguousarray(row_ids, dtype=np.uint32)

@@ -29,13 +29,14 @@ def math_parity():
         print('math', name, 'mismatch', bad); ok &= bad == 0
     return ok
 
-def scene_parity(name, W, H, spp, chunk=0, param=0, depth=50):
+def scene_parity(name, W, H, spp, chunk=0, param=0, depth=50, engine='wavefront'):
     s = rt.HostScene(name, seed=2022, param=param)
     cam, bg = s.default_view(W / H)
     p = rt.make_params(W, H, spp, depth, bg, seed=2022, spp_chunk=chunk)
     rows = rt.shuffled_rows(H, 7)
     ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=16, want_stats=True)
     dev = rt.DeviceScene(s.desc)
+    dev.set_engine(engine)
     t = time.time()
     out, st = dev.render(cam, p, rows, want_stats=True)
     dt = time.time() - t
@@ -45,17 +46,18 @@ def scene_parity(name, W, H, spp, chunk=0, param=0, depth=50):
     rel = np.abs(out[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1e-300)
     u8 = np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
     bit = (out.view(np.uint64) != ref.view(np.uint64)).sum()
-    print(f'{name} {W}x{H}x{spp} chunk={chunk}: counters_equal={same_cnt} nan_same={nan_same} max_rel={rel.max() if rel.size else 0:.3e} u8_equal={u8} bit_mismatch={bit}/{out.size} gpu_wall={dt:.3f}s kernel_ms={st.ms:.2f} info={dev.info()}')
+    print(f'[{engine}] {name} {W}x{H}x{spp} chunk={chunk}: counters_equal={same_cnt} nan_same={nan_same} max_rel={rel.max() if rel.size else 0:.3e} u8_equal={u8} bit_mismatch={bit}/{out.size} gpu_wall={dt:.3f}s kernel_ms={st.ms:.2f} info={dev.info()}')
     if not same_cnt:
         print('  gpu', st.as_dict()); print('  ref', st_ref.as_dict())
     return same_cnt and nan_same and u8 and (rel.max() if rel.size else 0) < 1e-9
 
-def timing(name, W, H, spp, chunk, param=0):
+def timing(name, W, H, spp, chunk, param=0, engine='wavefront'):
     s = rt.HostScene(name, seed=2022, param=param)
     cam, bg = s.default_view(W / H)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
     rows = np.arange(H, dtype=np.uint32)
     dev = rt.DeviceScene(s.desc)
+    dev.set_engine(engine)
     out, st = dev.render(cam, p, rows, want_stats=True)
     st2 = F.rt_stats()
     p2 = F.rt_params.from_buffer_copy(p)
@@ -64,7 +66,7 @@ def timing(name, W, H, spp, chunk, param=0):
     pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
     o = np.empty((len(rows), W, 3)); st3 = F.rt_stats()
     F.check(F.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), o.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st3)))
-    print(f'TIMING {name} {W}x{H}x{spp} chunk={chunk}: rays={st.rays} kernel_ms={st3.ms:.2f} Mrays/s={st.rays / st3.ms / 1e3:.1f} nodes/ray={st.node_visits / st.rays:.1f} (counter-run ms={st.ms:.2f})')
+    print(f'TIMING [{engine}] {name} {W}x{H}x{spp} chunk={chunk}: rays={st.rays} kernel_ms={st3.ms:.2f} Mrays/s={st.rays / st3.ms / 1e3:.1f} nodes/ray={st.node_visits / st.rays:.1f} (counter-run ms={st.ms:.2f})')
 
 if __name__ == '__main__':
     ok = math_parity()
@@ -78,6 +80,9 @@ if __name__ == '__main__':
     ok &= scene_parity('earth', 48, 32, 4)
     ok &= scene_parity('wwscene', 64, 36, 2)
     print('ALL OK' if ok else 'SOME FAILED')
-    timing('final_scene', 400, 400, 16, 8)
-    timing('random_scene', 600, 400, 16, 8)
-    timing('cornell_box', 300, 300, 32, 8)
+    ok2 = scene_parity('final_scene', 64, 64, 4, engine='mega') and scene_parity('cornell_smoke', 48, 48, 4, engine='mega')
+    print('MEGA OK' if ok2 else 'MEGA FAILED')
+    for eng in ('wavefront', 'mega'):
+        timing('final_scene', 800, 800, 20, 10, engine=eng)
+        timing('random_scene', 600, 400, 16, 8, engine=eng)
+        timing('cornell_box', 300, 300, 32, 8, engine=eng)
