@@ -34,13 +34,16 @@ enum Op : uint32_t {
     OP_COUNT = 8     // labels that take part in the vote
 };
 
-// Stack sentinels live in the unused kind codes 14 / 15 so that classify() is one table look-up.
+// Stack sentinels live in the unused kind codes 12..15 so that classify() is one table look-up.
+constexpr uint32_t REF_MED1 = 12u << RT_REF_KIND_SHIFT;       // medium: first boundary query finished
+constexpr uint32_t REF_MED2 = 13u << RT_REF_KIND_SHIFT;       // medium: second boundary query finished
 constexpr uint32_t REF_EMPTY = 14u << RT_REF_KIND_SHIFT;      // stack exhausted
 constexpr uint32_t REF_POPCTX = 15u << RT_REF_KIND_SHIFT;     // leave the innermost mover
 
 RT_DEV uint32_t classify(uint32_t ref) {
     // kind -> op, 4 bits per kind (NODE..LIST, 12/13 unused, EMPTY, POPCTX)
-    const unsigned long long table = ((unsigned long long)OP_SHADE << 56) | ((unsigned long long)OP_CTX << 60) | (unsigned long long)OP_NODE | ((unsigned long long)OP_SPHERE << 4) | ((unsigned long long)OP_SPHERE << 8) |
+    const unsigned long long table = ((unsigned long long)OP_MEDIUM << 48) | ((unsigned long long)OP_MEDIUM << 52) |
+                                     ((unsigned long long)OP_SHADE << 56) | ((unsigned long long)OP_CTX << 60) | (unsigned long long)OP_NODE | ((unsigned long long)OP_SPHERE << 4) | ((unsigned long long)OP_SPHERE << 8) |
                                      ((unsigned long long)OP_RECT << 12) | ((unsigned long long)OP_BOX << 16) | ((unsigned long long)OP_MISC << 20) |
                                      ((unsigned long long)OP_MISC << 24) | ((unsigned long long)OP_MEDIUM << 28) | ((unsigned long long)OP_CTX << 32) |
                                      ((unsigned long long)OP_CTX << 36) | ((unsigned long long)OP_CTX << 40) | ((unsigned long long)OP_CTX << 44);
@@ -186,10 +189,12 @@ RT_DEV Vec3 moving_center(const rt_moving_sphere &q, double time) {   // sphere.
 // X?Rect::hit, aarect.rs:46-56 (and the XZ / YZ twins).
 RT_DEV bool rect_t(uint32_t axis, double a0, double a1, double b0, double b1, double k, const XRay &r,
                    double t_min, double t_max, double &t) {
-    double ok, dk, oa, da, ob, db;
-    if (axis == RT_RECT_XY) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-    else if (axis == RT_RECT_XZ) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
-    else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+    // (select values, not addresses: a phi over &r.o.x / &r.o.y keeps the ray in scratch memory)
+    const double ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    const bool xy = axis == RT_RECT_XY, xz = axis == RT_RECT_XZ;
+    const double ok = xy ? oz : xz ? oy : ox, dk = xy ? dz : xz ? dy : dx;
+    const double oa = (xy || xz) ? ox : oy, da = (xy || xz) ? dx : dy;
+    const double ob = xy ? oy : oz, db = xy ? dy : dz;
     double tt = (k - ok) / dk;
     if (tt < t_min || tt > t_max) return false;
     double a = oa + tt * da;
@@ -304,11 +309,11 @@ RT_DEV void sphere_uv(Vec3 p, double &u, double &v) {
 }
 
 RT_DEV void rect_record(const RectP &q, uint32_t mat, const XRay &r, double t, HitRec &rec) {   // aarect.rs:51-71
-    double oa, da, ob, db;
-    Vec3 outward_normal;
-    if (q.axis == RT_RECT_XY) { oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; outward_normal = Vec3(0.0, 0.0, 1.0); }
-    else if (q.axis == RT_RECT_XZ) { oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; outward_normal = Vec3(0.0, 1.0, 0.0); }
-    else { oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; outward_normal = Vec3(1.0, 0.0, 0.0); }
+    const double ox = r.o.x, oy = r.o.y, oz = r.o.z, dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    const bool xy = q.axis == RT_RECT_XY, xz = q.axis == RT_RECT_XZ;
+    const double oa = (xy || xz) ? ox : oy, da = (xy || xz) ? dx : dy;
+    const double ob = xy ? oy : oz, db = xy ? dy : dz;
+    const Vec3 outward_normal(xy || xz ? 0.0 : 1.0, xz ? 1.0 : 0.0, xy ? 1.0 : 0.0);
     double a = oa + t * da;
     double b = ob + t * db;
     rec.p = r.o + r.d * t;

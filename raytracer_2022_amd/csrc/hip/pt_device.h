@@ -90,12 +90,17 @@ constexpr int kBlock = 256;
 // Launchers (pt_kernel.hip). `stack_need` = entries the scene needs (host-computed).
 hipError_t launch_render(const SceneDev &scene, const RenderArgs &args, uint32_t stack_need, bool counters,
                          int n_blocks_hint, hipStream_t stream);
+// Arms of the traversal kernel a scene can reach (template FEAT of wf_trace).
+constexpr unsigned kFeatMisc = 1;      // triangles, rings
+constexpr unsigned kFeatMovers = 2;    // Translate / RotateY / Zoom, HittableList objects
+constexpr unsigned kFeatVolumes = 4;   // Boxes, ConstantMedium
+
 // Wavefront engine: alternates shade / trace passes over the pool until it drains.
 // Blocks the calling thread (polls `n_active`). d_scene / d_args / d_pool are the
 // device-resident copies of the three structs.
 hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
-                                   const WfPool &pool, uint32_t stack_need, bool counters, uint32_t *h_active_pinned,
-                                   hipStream_t stream, uint32_t *out_iterations);
+                                   const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
+                                   uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

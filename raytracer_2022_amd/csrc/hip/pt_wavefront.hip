@@ -344,6 +344,14 @@ struct TLane {
     double a_len;          // cur.d.length_sqr()  (sphere.rs:41, hoisted likewise)
     double tm;
     double closest;
+    // ConstantMedium::hit asks its boundary two closest-hit questions of its own
+    // (constantmedium.rs:50-51). They run through the same operations as the main query,
+    // against (t_lo, sub_closest) instead of (t_min, closest), and never touch the winner.
+    double t_lo;           // lower bound in force: a.t_min, or the sub-query's
+    double sub_closest;
+    double med_t1;
+    uint32_t med_ref;      // the medium being evaluated (0 = none: main query)
+    bool sub_found;
     Rng rng;
     Chain ctx;
     Chain win_chain;
@@ -366,7 +374,9 @@ RT_DEV void t_set_cur(TLane &L, const XRay &c) {
     L.inv = Vec3(1.0 / c.d.x, 1.0 / c.d.y, 1.0 / c.d.z);
     L.a_len = c.d.length_sqr();
 }
+RT_DEV double t_hi(const TLane &L) { return L.med_ref ? L.sub_closest : L.closest; }
 RT_DEV void t_accept(TLane &L, double t, uint32_t face) {
+    if (L.med_ref) { L.sub_closest = t; L.sub_found = true; return; }
     L.closest = t;
     L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx;
 }
@@ -378,7 +388,9 @@ RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
 
 } // namespace
 
-template <int STACK, bool STATS>
+// FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
+// worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
+template <int STACK, bool STATS, unsigned FEAT>
 __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
                                                    const WfPool *__restrict__ pp) {
     __shared__ uint32_t stack_lds[STACK * kBlock];
@@ -417,6 +429,7 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
     TLane L;
     L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
+    L.t_lo = a.t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
     const double t_min = a.t_min;
@@ -437,7 +450,7 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                 double bmin[3] = {rtm::u2d(((uint64_t)q0.y << 32) | q0.x), rtm::u2d(((uint64_t)q0.w << 32) | q0.z), rtm::u2d(((uint64_t)q1.y << 32) | q1.x)};
                 double bmax[3] = {rtm::u2d(((uint64_t)q1.w << 32) | q1.z), rtm::u2d(((uint64_t)q2.y << 32) | q2.x), rtm::u2d(((uint64_t)q2.w << 32) | q2.z)};
                 uint32_t left = q3.x, right = q3.y;
-                double tmn = t_min, tmx = L.closest;
+                double tmn = L.t_lo, tmx = t_hi(L);
                 bool miss = false;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
@@ -471,7 +484,7 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
         } else if (best == OP_NODE) {
             cnt.node();
             const rt_bvh_node &n = s.nodes[RT_REF_INDEX(L.top)];
-            double tmn = t_min, tmx = L.closest;
+            double tmn = L.t_lo, tmx = t_hi(L);
             bool miss = false;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -493,47 +506,73 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
             if (kind == RT_KIND_SPHERE) { const rt_sphere &q = s.spheres[idx]; center = ld3(q.center); radius = q.radius; }
             else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
             double t;
-            if (sphere_t(center, radius, L.cur, L.a_len, t_min, L.closest, t)) t_accept(L, t, 0);
+            if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
             t_next(L, st);
         } else if (best == OP_RECT) {
             cnt.prim(RT_KIND_RECT);
             const rt_rect &q = s.rects[RT_REF_INDEX(L.top)];
             double t;
-            if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, L.cur, t_min, L.closest, t)) t_accept(L, t, 0);
+            if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, L.cur, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
             t_next(L, st);
-        } else if (best == OP_BOX) {
+        } else if ((FEAT & kFeatVolumes) && best == OP_BOX) {
             cnt.prim(RT_KIND_BOX);
             double t;
             uint32_t face = 0;
-            if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, t_min, L.closest, t, face)) t_accept(L, t, face);
+            if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face);
             t_next(L, st);
-        } else if (best == OP_MEDIUM) {                               // ConstantMedium::hit, constantmedium.rs:49-83
-            cnt.prim(RT_KIND_MEDIUM);
-            const rt_medium &m = s.media[RT_REF_INDEX(L.top)];
-            double t1, t2;
-            if (boundary_t<STATS>(s, m.boundary, L.cur, L.tm, -rtm::INF, rtm::INF, t1, cnt) &&
-                boundary_t<STATS>(s, m.boundary, L.cur, L.tm, t1 + 0.0001, rtm::INF, t2, cnt)) {
-                t1 = rtm::fmax_(t1, t_min);
-                t2 = rtm::fmin_(t2, L.closest);
-                if (!(t1 >= t2)) {
-                    t1 = rtm::fmax_(t1, 0.0);
-                    double ray_length = L.cur.d.length();
-                    double distance_inside_boundary = (t2 - t1) * ray_length;
-                    double rnd = L.rng.gen_f64();
-                    double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
-                    if (!(hit_distance > distance_inside_boundary)) t_accept(L, t1 + hit_distance / ray_length, 0);
+        } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83
+            if (L.top == REF_MED1) {                                  // boundary.hit(r, -inf, inf) is back
+                if (L.sub_found) {
+                    L.med_t1 = L.sub_closest;
+                    L.t_lo = L.med_t1 + 0.0001;                       // boundary.hit(r, rec1.t + 0.0001, inf)
+                    L.sub_closest = rtm::INF; L.sub_found = false;
+                    st.push(L, REF_MED2);
+                    L.top = s.media[RT_REF_INDEX(L.med_ref)].boundary;
+                    L.op = classify(L.top);
+                } else {
+                    L.med_ref = 0; L.t_lo = t_min;
+                    t_next(L, st);
                 }
+            } else if (L.top == REF_MED2) {
+                uint32_t mref = L.med_ref;
+                bool both = L.sub_found;
+                double t2 = L.sub_closest;
+                L.med_ref = 0; L.t_lo = t_min;                        // back in the main query
+                if (both) {
+                    const rt_medium &m = s.media[RT_REF_INDEX(mref)];
+                    double t1 = rtm::fmax_(L.med_t1, t_min);
+                    t2 = rtm::fmin_(t2, L.closest);
+                    if (!(t1 >= t2)) {
+                        t1 = rtm::fmax_(t1, 0.0);
+                        double ray_length = L.cur.d.length();
+                        double distance_inside_boundary = (t2 - t1) * ray_length;
+                        double rnd = L.rng.gen_f64();
+                        double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
+                        if (!(hit_distance > distance_inside_boundary)) {
+                            L.top = mref;                             // the medium itself is the winning leaf
+                            t_accept(L, t1 + hit_distance / ray_length, 0);
+                        }
+                    }
+                }
+                t_next(L, st);
+            } else {                                                  // a medium leaf: start its first boundary query
+                cnt.prim(RT_KIND_MEDIUM);
+                L.med_ref = L.top;
+                L.t_lo = -rtm::INF;
+                L.sub_closest = rtm::INF; L.sub_found = false;
+                st.push(L, REF_MED1);
+                L.top = s.media[RT_REF_INDEX(L.top)].boundary;
+                L.op = classify(L.top);
             }
-            t_next(L, st);
-        } else if (best == OP_MISC) {                                 // Triangle, Ring
+        } else if ((FEAT & kFeatMisc) && best == OP_MISC) {                                 // Triangle, Ring
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
             cnt.prim(kind);
             double t;
-            bool h = kind == RT_KIND_TRIANGLE ? triangle_t(s.triangles[idx], L.cur, t_min, L.closest, t)
-                                              : ring_t(s.rings[idx], L.cur, t_min, L.closest, t);
+            bool h = kind == RT_KIND_TRIANGLE ? triangle_t(s.triangles[idx], L.cur, L.t_lo, t_hi(L), t)
+                                              : ring_t(s.rings[idx], L.cur, L.t_lo, t_hi(L), t);
             if (h) t_accept(L, t, 0);
             t_next(L, st);
-        } else if (best == OP_CTX) {                                  // movers in / out, HittableList expansion
+        } else if ((FEAT & kFeatMovers) && best == OP_CTX) {                                  // movers in / out, HittableList expansion
             if (L.top == REF_POPCTX) {
                 L.ctx.n--;
                 Ray wr = pv.load_ray(L.slot);
@@ -556,7 +595,7 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                     t_next(L, st);
                 }
             }
-        } else {
+        } else if (best == OP_SHADE) {
             // OP_SHADE here = "this lane's traversal is finished (or it has no ray yet)":
             // publish the winner, then pull the next ray from the block's list.
             if (L.has_ray) {
@@ -595,6 +634,7 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                 L.rng = Rng(pool.rng[L.slot]);
                 t_set_cur(L, XRay{wr.orig, wr.dir});
                 L.closest = rtm::F64_MAX;
+                L.t_lo = t_min; L.med_ref = 0;
                 L.win_leaf = REF_EMPTY; L.win_face = 0;
                 L.ctx.n = 0;
                 L.sp = 0;
@@ -614,14 +654,27 @@ template <bool STATS>
 static void launch_shade(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
     hipLaunchKernelGGL((wf_shade<STATS>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
 }
-template <int STACK, bool STATS>
+template <int STACK, bool STATS, unsigned FEAT>
 static void launch_trace(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((wf_trace<STACK, STATS>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+}
+template <int STACK>
+static void launch_trace_feat(unsigned feat, const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
+    switch (feat & 7u) {
+        case 0: launch_trace<STACK, false, 0>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 1: launch_trace<STACK, false, 1>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 2: launch_trace<STACK, false, 2>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 3: launch_trace<STACK, false, 3>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 4: launch_trace<STACK, false, 4>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 5: launch_trace<STACK, false, 5>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 6: launch_trace<STACK, false, 6>(d_scene, d_args, d_pool, blocks, stream); break;
+        default: launch_trace<STACK, false, 7>(d_scene, d_args, d_pool, blocks, stream); break;
+    }
 }
 
 hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
-                                   const WfPool &pool, uint32_t stack_need, bool counters, uint32_t *h_active_pinned,
-                                   hipStream_t stream, uint32_t *out_iterations) {
+                                   const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
+                                   uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const uint32_t blocks = pool.n_blocks;
     hipError_t e;
@@ -635,11 +688,11 @@ hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_
             if (counters) launch_shade<true>(d_scene, d_args, d_pool, blocks, stream);
             else launch_shade<false>(d_scene, d_args, d_pool, blocks, stream);
             if (stack_need <= (uint32_t)kStackSmall) {
-                if (counters) launch_trace<kStackSmall, true>(d_scene, d_args, d_pool, blocks, stream);
-                else launch_trace<kStackSmall, false>(d_scene, d_args, d_pool, blocks, stream);
+                if (counters) launch_trace<kStackSmall, true, 7>(d_scene, d_args, d_pool, blocks, stream);
+                else launch_trace_feat<kStackSmall>(features, d_scene, d_args, d_pool, blocks, stream);
             } else {
-                if (counters) launch_trace<kStackLarge, true>(d_scene, d_args, d_pool, blocks, stream);
-                else launch_trace<kStackLarge, false>(d_scene, d_args, d_pool, blocks, stream);
+                if (counters) launch_trace<kStackLarge, true, 7>(d_scene, d_args, d_pool, blocks, stream);
+                else launch_trace_feat<kStackLarge>(features, d_scene, d_args, d_pool, blocks, stream);
             }
             iterations++;
         }

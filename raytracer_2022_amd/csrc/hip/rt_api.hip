@@ -220,7 +220,8 @@ struct rt_scene {
     SceneDev dev{};
     std::vector<void *> owned;
     uint32_t stack_need = 1;
-    uint32_t node_quorum = 24;
+    unsigned features = 7;
+    uint32_t node_quorum = 12;
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     int max_pool_blocks = 0;          // 0 = 4 x CUs
     int device = 0;
@@ -351,7 +352,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
         RT_HIP(hipEventRecord(w.ev0, stream));
         if (a.n_items > 0) {
-            RT_HIP(launch_render_wavefront(w.d_scene, w.d_args, w.d_pool, w.pool, sc->stack_need, counters, w.h_active, stream, &w.iterations));
+            RT_HIP(launch_render_wavefront(w.d_scene, w.d_args, w.d_pool, w.pool, sc->stack_need, sc->features, counters, w.h_active, stream, &w.iterations));
             if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
         RT_HIP(hipEventRecord(w.ev1, stream));
@@ -448,6 +449,9 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.root = desc->root;
             s.n_lights = desc->n_lights;
             sc->stack_need = (uint32_t)need;
+            sc->features = ((desc->n_triangles || desc->n_rings) ? kFeatMisc : 0u) |
+                           ((desc->n_xforms || desc->n_lists) ? kFeatMovers : 0u) |
+                           ((desc->n_boxes || desc->n_media) ? kFeatVolumes : 0u);
         } catch (...) {
             for (void *p : sc->owned) (void)hipFree(p);
             delete sc;

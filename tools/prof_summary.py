@@ -12,22 +12,27 @@ print('== kernel trace (megakernel dispatches) ==')
 for f in find('*kernel_trace.csv'):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if 'pt_megakernel' in row.get('Kernel_Name', ''):
+            if any(k in row.get('Kernel_Name', '') for k in ('pt_megakernel',)):
                 dur = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e6
                 print('dispatch', row.get('Dispatch_Id'), 'ms=%.3f' % dur, 'VGPR', row.get('VGPR_Count'), 'accum', row.get('Accum_VGPR_Count'), 'SGPR', row.get('SGPR_Count'),
                       'LDS', row.get('LDS_Block_Size'), 'scratch', row.get('Scratch_Size'), 'grid', row.get('Grid_Size_X'), 'wg', row.get('Workgroup_Size_X'))
 print('== counters (summed over megakernel dispatches) ==')
-tot = collections.defaultdict(float); ndisp = collections.defaultdict(set)
-for f in find('*counter_collection.csv'):
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            if 'pt_megakernel' in row.get('Kernel_Name', ''):
-                tot[row['Counter_Name']] += float(row['Counter_Value']); ndisp[row['Counter_Name']].add(row['Dispatch_Id'])
-for k in sorted(tot):
-    print('%-28s total=%.6g dispatches=%d per_dispatch=%.6g' % (k, tot[k], len(ndisp[k]), tot[k] / max(1, len(ndisp[k]))))
-g = lambda k: tot.get(k, 0.0) / max(1, len(ndisp.get(k, [1])))
-if g('SQ_ACTIVE_INST_VALU'):
-    print('lane utilisation (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)) = %.3f' % (g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64)))
-if g('SQ_WAVE_CYCLES'):
-    print('VALU active / wave cycles = %.3f   wait_any / wave cycles = %.3f   wait_inst_any / wave cycles = %.3f' % (
-        g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'), g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES')))
+for kname in ('pt_megakernel', 'wf_trace', 'wf_shade'):
+    tot = collections.defaultdict(float); ndisp = collections.defaultdict(set)
+    for f in find('*counter_collection.csv'):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if kname in row.get('Kernel_Name', '') and 'true>' not in row.get('Kernel_Name', '').replace('Lb1', 'true>'):
+                    tot[row['Counter_Name']] += float(row['Counter_Value']); ndisp[row['Counter_Name']].add(row['Dispatch_Id'])
+    if not tot: continue
+    print('-- %s (non-counter variant) --' % kname)
+    for k in sorted(tot):
+        print('%-28s total=%.6g dispatches=%d' % (k, tot[k], len(ndisp[k])))
+    g = lambda k: tot.get(k, 0.0)
+    if g('SQ_ACTIVE_INST_VALU'):
+        # calibration (tools/calib_util.py): a fully active f64 kernel reads 0.47 in this formula
+        print('lane utilisation raw (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)) = %.3f  (/0.47 calibrated = %.2f)' % (
+            g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64), g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64) / 0.47))
+    if g('SQ_WAVE_CYCLES'):
+        print('VALU active / wave cycles = %.3f   wait_any / wave cycles = %.3f   wait_inst_any / wave cycles = %.3f' % (
+            g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'), g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'), g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES')))

@@ -1,0 +1,30 @@
+"""Wavefront engine tuning probe: Mrays/s for pool sizes / chunk sizes / node quorum."""
+import sys, os, time, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, ctypes as C
+import raytracer_2022_amd as rt
+from raytracer_2022_amd import _ffi as F
+
+def run(dev, cam, p, rows, W):
+    pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
+    o = np.empty((len(rows), W, 3)); st = F.rt_stats()
+    F.check(F.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), o.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+    return st.ms
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'final_scene'
+W = H = 800; spp = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+s = rt.HostScene(name, seed=2022)
+cam, bg = s.default_view(W / H)
+rows = np.arange(H, dtype=np.uint32)
+dev = rt.DeviceScene(s.desc)
+p0 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
+out, st = dev.render(cam, p0, rows, want_stats=True)
+rays = st.rays
+print('rays', rays, flush=True)
+cfgs = [('wavefront', b, 1, q) for b in (768, 1024, 1280) for q in (8, 12)] + [('mega', 0, 2, 8)]
+for eng, blocks, chunk, q in cfgs:
+    dev.set_engine(eng, blocks); dev.set_tuning(q)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
+    run(dev, cam, p, rows, W)
+    ms = run(dev, cam, p, rows, W)
+    print(f'{eng} blocks={blocks} chunk={chunk} quorum={q}: {ms:.1f} ms  {rays / ms / 1e3:.1f} Mrays/s', flush=True)
