@@ -66,12 +66,11 @@ struct WfPool {
     uint32_t n_slots;
     uint32_t n_blocks;
     uint8_t *kind;          // [P]    what the slot waits for (SlotKind)
-    double *ray;            // [7][P] ox oy oz dx dy dz tm  (world frame)
-    uint64_t *rng;          // [P]    path RNG state
-    double *hit_t;          // [P]
-    uint32_t *hit_leaf;     // [P]    winning leaf ref
-    uint32_t *hit_meta;     // [P]    box face | movers << 4
-    uint32_t *hit_chain;    // [4][P] enclosing movers (valid entries: movers)
+    // One 64-byte record per slot: {ox oy oz dx dy dz tm, rng state} — exactly one cache line,
+    // so a lane fetches its ray with four 16-byte loads whatever order the slots are visited in.
+    double *ray;            // [P][8]
+    // One 32-byte record per slot: {t (f64), leaf ref, box face | movers << 4, 4 mover refs}.
+    uint32_t *hit;          // [P][8]
     uint64_t *item;         // [P]    pixel slot * n_chunks + chunk
     uint32_t *smp;          // [P]    next sample of the item
     uint32_t *smp_end;      // [P]
@@ -83,7 +82,7 @@ struct WfPool {
 };
 
 // Traversal-stack capacities the megakernel is instantiated for.
-constexpr int kStackSmall = 24;
+constexpr int kStackSmall = 22;   // 22 KiB of stack + 8 KiB ray list: five workgroups fit a CU's 160 KiB of LDS
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
 

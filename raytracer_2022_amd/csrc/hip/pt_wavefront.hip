@@ -46,17 +46,38 @@ constexpr int S = kSlotsPerBlock;
 
 struct PoolView {
     const WfPool &p;
-    RT_DEV Ray load_ray(uint32_t slot) const {
-        const double *q = p.ray + slot;
-        uint64_t P = p.n_slots;
-        return Ray(Vec3(q[0], q[P], q[2 * P]), Vec3(q[3 * P], q[4 * P], q[5 * P]), q[6 * P]);
+    // Ray + RNG state: one 64-byte line per slot.
+    RT_DEV Ray load_ray(uint32_t slot, uint64_t &rng_state) const {
+        const double2 *q = reinterpret_cast<const double2 *>(p.ray + (uint64_t)slot * 8);
+        double2 a = q[0], b = q[1], c = q[2], d = q[3];
+        rng_state = rtm::d2u(d.y);
+        return Ray(Vec3(a.x, a.y, b.x), Vec3(b.y, c.x, c.y), d.x);
     }
-    RT_DEV void store_ray(uint32_t slot, const Ray &r) const {
-        double *q = p.ray + slot;
-        uint64_t P = p.n_slots;
-        q[0] = r.orig.x; q[P] = r.orig.y; q[2 * P] = r.orig.z;
-        q[3 * P] = r.dir.x; q[4 * P] = r.dir.y; q[5 * P] = r.dir.z;
-        q[6 * P] = r.tm;
+    RT_DEV Ray load_ray(uint32_t slot) const { uint64_t unused; return load_ray(slot, unused); }
+    RT_DEV void store_ray(uint32_t slot, const Ray &r, uint64_t rng_state) const {
+        double2 *q = reinterpret_cast<double2 *>(p.ray + (uint64_t)slot * 8);
+        q[0] = make_double2(r.orig.x, r.orig.y);
+        q[1] = make_double2(r.orig.z, r.dir.x);
+        q[2] = make_double2(r.dir.y, r.dir.z);
+        q[3] = make_double2(r.tm, rtm::u2d(rng_state));
+    }
+    RT_DEV void store_rng(uint32_t slot, uint64_t rng_state) const { p.ray[(uint64_t)slot * 8 + 7] = rtm::u2d(rng_state); }
+    // Winner of the traversal: one 32-byte record per slot.
+    RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch) const {
+        uint4 *q = reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8);
+        uint64_t tb = rtm::d2u(t);
+        q[0] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta);
+        if (ch.n > 0) q[1] = make_uint4(ch.c0, ch.c1, ch.c2, ch.c3);
+    }
+    RT_DEV void load_hit(uint32_t slot, Winner &w) const {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p.hit + (uint64_t)slot * 8);
+        uint4 a = q[0];
+        w.t = rtm::u2d(((uint64_t)a.y << 32) | a.x);
+        w.leaf = a.z;
+        w.face = a.w & 0xFu;
+        w.chain.n = a.w >> 4;
+        w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
+        if (w.chain.n > 0) { uint4 b = q[1]; w.chain.c0 = b.x; w.chain.c1 = b.y; w.chain.c2 = b.z; w.chain.c3 = b.w; }
     }
 };
 
@@ -156,27 +177,16 @@ __global__ void __launch_bounds__(kBlock) wf_shade(const SceneDev *__restrict__ 
         SlotTape tape{pool.tape, pool.n_slots, slot};
 
         if (on && kind >= SK_MISS) {
-            r = pv.load_ray(slot);
-            rng = Rng(pool.rng[slot]);
+            uint64_t rs;
+            r = pv.load_ray(slot, rs);
+            rng = Rng(rs);
             depth = pool.depth[slot];
             if (kind == SK_MISS) {
                 Lterm = background;                                   // main.rs:275-276
                 ended = true;
             } else {
                 Winner w;
-                w.t = pool.hit_t[slot];
-                w.leaf = pool.hit_leaf[slot];
-                uint32_t meta = pool.hit_meta[slot];
-                w.face = meta & 0xFu;
-                w.chain.n = meta >> 4;
-                w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
-                if (w.chain.n > 0) {
-                    uint64_t P = pool.n_slots;
-                    w.chain.c0 = pool.hit_chain[slot];
-                    w.chain.c1 = pool.hit_chain[P + slot];
-                    w.chain.c2 = pool.hit_chain[2 * P + slot];
-                    w.chain.c3 = pool.hit_chain[3 * P + slot];
-                }
+                pv.load_hit(slot, w);
                 HitRec rec;
                 winner_record(s, r, w, rec);
                 const rt_material &mat = s.materials[rec.mat];
@@ -316,8 +326,7 @@ __global__ void __launch_bounds__(kBlock) wf_shade(const SceneDev *__restrict__ 
         if (on) {
             if (alive) {
                 cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
-                pv.store_ray(slot, r);
-                pool.rng[slot] = rng.s;
+                pv.store_ray(slot, r, rng.s);
                 pool.depth[slot] = depth;
                 pool.kind[slot] = (uint8_t)SK_TRACE;
                 my_traced++;
@@ -391,7 +400,7 @@ RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT>
-__global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
+__global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & kFeatMisc) ? 4 : 5) wf_trace(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
                                                    const WfPool *__restrict__ pp) {
     __shared__ uint32_t stack_lds[STACK * kBlock];
     __shared__ uint16_t list[S];
@@ -463,7 +472,13 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                     miss = miss || (tmx <= tmn);
                 }
                 if (!miss) {
-                    st.push(L, right);
+                    // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
+                    // primitive a second time against t_max = its own t finds the same hit again, so
+                    // only the count of tests is kept; anything that can draw from the RNG or carry
+                    // movers (media, movers, nodes, lists) is really visited twice.
+                    uint32_t lk = RT_REF_KIND(left);
+                    if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
+                    else st.push(L, right);
                     L.top = left;
                 } else {
                     L.top = st.pop(L);
@@ -496,8 +511,15 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                 tmx = t1 < tmx ? t1 : tmx;
                 miss = miss || (tmx <= tmn);
             }
-            if (!miss) { st.push(L, n.right); L.top = n.left; L.op = classify(L.top); }
-            else t_next(L, st);
+            if (!miss) {
+                uint32_t left = n.left, right = n.right, lk = RT_REF_KIND(left);
+                if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
+                else st.push(L, right);
+                L.top = left;
+                L.op = classify(L.top);
+            } else {
+                t_next(L, st);
+            }
         } else if (best == OP_SPHERE) {                               // Sphere / MovingSphere::hit
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
             cnt.prim(kind);
@@ -603,22 +625,13 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
                 bool found = L.win_leaf != REF_EMPTY;
                 uint32_t kind = SK_MISS;
                 if (found) {
-                    uint64_t P = pool.n_slots;
-                    pool.hit_t[slot] = L.closest;
-                    pool.hit_leaf[slot] = L.win_leaf;
-                    pool.hit_meta[slot] = L.win_face | (L.win_chain.n << 4);
-                    if (L.win_chain.n > 0) {
-                        pool.hit_chain[slot] = L.win_chain.c0;
-                        pool.hit_chain[P + slot] = L.win_chain.c1;
-                        pool.hit_chain[2 * P + slot] = L.win_chain.c2;
-                        pool.hit_chain[3 * P + slot] = L.win_chain.c3;
-                    }
+                    pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4), L.win_chain);
                     uint32_t mk = s.materials[leaf_material(s, L.win_leaf)].kind;
                     kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_LAMBERTIAN ? SK_LAMBERTIAN
                          : mk == RT_MAT_METAL ? SK_METAL : mk == RT_MAT_DIELECTRIC ? SK_DIELECTRIC : SK_ISOTROPIC;
                 }
                 pool.kind[slot] = (uint8_t)kind;
-                if (L.rng.draws) { pool.rng[slot] = L.rng.s; cnt.draws(L.rng.draws); }
+                if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
             unsigned long long m = __ballot(true);
@@ -629,9 +642,10 @@ __global__ void __launch_bounds__(kBlock) wf_trace(const SceneDev *__restrict__ 
             uint32_t mine = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (mine < n_list) {
                 L.slot = base + list[mine];
-                Ray wr = pv.load_ray(L.slot);
+                uint64_t rs;
+                Ray wr = pv.load_ray(L.slot, rs);
                 L.tm = wr.tm;
-                L.rng = Rng(pool.rng[L.slot]);
+                L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir});
                 L.closest = rtm::F64_MAX;
                 L.t_lo = t_min; L.med_ref = 0;

@@ -223,7 +223,7 @@ struct rt_scene {
     unsigned features = 7;
     uint32_t node_quorum = 12;
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
-    int max_pool_blocks = 0;          // 0 = 4 x CUs
+    int max_pool_blocks = 0;          // 0 = 5 x CUs
     int device = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
@@ -282,12 +282,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.n_slots = slots;
     q.n_blocks = blocks;
     q.kind = pool_alloc<uint8_t>(w, P);
-    q.ray = pool_alloc<double>(w, 7 * P);
-    q.rng = pool_alloc<uint64_t>(w, P);
-    q.hit_t = pool_alloc<double>(w, P);
-    q.hit_leaf = pool_alloc<uint32_t>(w, P);
-    q.hit_meta = pool_alloc<uint32_t>(w, P);
-    q.hit_chain = pool_alloc<uint32_t>(w, 4 * P);
+    q.ray = pool_alloc<double>(w, 8 * P);
+    q.hit = pool_alloc<uint32_t>(w, 8 * P);
     q.item = pool_alloc<uint64_t>(w, P);
     q.smp = pool_alloc<uint32_t>(w, P);
     q.smp_end = pool_alloc<uint32_t>(w, P);
@@ -339,7 +335,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Wavefront engine: pool of path slots, shade / trace passes until it drains.
         hipDeviceProp_t prop;
         RT_HIP(hipGetDeviceProperties(&prop, sc->device));
-        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 4u * (uint32_t)prop.multiProcessorCount;
+        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 5u * (uint32_t)prop.multiProcessorCount;
         uint64_t want = (a.n_items + kSlotsPerBlock - 1) / kSlotsPerBlock;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
         ensure_pool(w, blocks, p->max_depth, stream);
