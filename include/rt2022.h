@@ -75,6 +75,7 @@ typedef struct rt_bvh_node {
     double   bmax[3];
     uint32_t left;
     uint32_t right;
+    uint32_t _pad[2];                 /* one node = one 64-byte line = four 16-byte loads */
 } rt_bvh_node;
 
 typedef struct rt_sphere {            /* 40 B */

@@ -43,7 +43,7 @@ d3 = C.c_double * 3
 
 
 class rt_bvh_node(C.Structure):
-    _fields_ = [("bmin", d3), ("bmax", d3), ("left", C.c_uint32), ("right", C.c_uint32)]
+    _fields_ = [("bmin", d3), ("bmax", d3), ("left", C.c_uint32), ("right", C.c_uint32), ("_pad", C.c_uint32 * 2)]
 
 
 class rt_sphere(C.Structure):

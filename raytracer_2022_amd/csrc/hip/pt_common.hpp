@@ -326,7 +326,9 @@ RT_DEV void rect_record(const RectP &q, uint32_t mat, const XRay &r, double t, H
 
 // The HitRecord of the winning candidate, rebuilt from (leaf, t) in the leaf's own
 // frame and then carried out through its movers.
-RT_DEV void winner_record(const SceneDev &s, const Ray &wr, const Winner &w, HitRec &rec) {
+// `want_uv` = false skips the sphere's acos / atan2 when no texture will read (u, v): a pure
+// function of the hit, so leaving it out cannot change anything else.
+RT_DEV void winner_record(const SceneDev &s, const Ray &wr, const Winner &w, HitRec &rec, bool want_uv = true) {
     const XRay world{wr.orig, wr.dir};
     XRay r = ray_at_level(s, w.chain, w.chain.n, world);
     uint32_t kind = RT_REF_KIND(w.leaf), idx = RT_REF_INDEX(w.leaf);
@@ -338,7 +340,8 @@ RT_DEV void winner_record(const SceneDev &s, const Ray &wr, const Winner &w, Hit
             else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, wr.tm); radius = q.radius; mat = q.mat; }
             Vec3 at = r.o + r.d * t;
             Vec3 outward_normal = (at - center) / radius;
-            sphere_uv(outward_normal, rec.u, rec.v);
+            rec.u = 0.0; rec.v = 0.0;
+            if (want_uv) sphere_uv(outward_normal, rec.u, rec.v);
             rec.p = at; rec.t = t; rec.mat = mat;
             rec.set_face_normal(r.d, outward_normal);
             break;

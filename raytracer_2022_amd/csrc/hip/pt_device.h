@@ -95,9 +95,8 @@ constexpr unsigned kFeatMovers = 2;    // Translate / RotateY / Zoom, HittableLi
 constexpr unsigned kFeatVolumes = 4;   // Boxes, ConstantMedium
 
 // Wavefront engine: alternates shade / trace passes over the pool until it drains.
-// Blocks the calling thread (polls `n_active`). d_scene / d_args / d_pool are the
-// device-resident copies of the three structs.
-hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
+// Blocks the calling thread (polls `n_active`). d_args is the device-resident copy of `args`.
+hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                    uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);

@@ -120,15 +120,12 @@ RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
 // Shade pass.
 // =====================================================================================
 template <bool STATS>
-__global__ void __launch_bounds__(kBlock) wf_shade(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
-                                                   const WfPool *__restrict__ pp) {
+__global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool) {
     __shared__ uint32_t hist[SK_COUNT];
     __shared__ uint32_t cursor[SK_COUNT];
     __shared__ uint32_t sorted[S];
     __shared__ uint32_t n_sorted, n_traced;
-    const SceneDev &s = *sp;
     const RenderArgs &a = *ap;
-    const WfPool &pool = *pp;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
     const uint32_t tid = threadIdx.x;
@@ -187,9 +184,15 @@ __global__ void __launch_bounds__(kBlock) wf_shade(const SceneDev *__restrict__ 
             } else {
                 Winner w;
                 pv.load_hit(slot, w);
+                // (u, v) only matter to image textures (and to a checker that may select one).
+                const rt_material &mat = s.materials[leaf_material(s, w.leaf)];
+                bool want_uv = false;
+                if (kind == SK_LIGHT || kind == SK_LAMBERTIAN || kind == SK_ISOTROPIC) {
+                    uint32_t tk = s.textures[mat.tex].kind;
+                    want_uv = tk == RT_TEX_IMAGE || tk == RT_TEX_CHECKER;
+                }
                 HitRec rec;
-                winner_record(s, r, w, rec);
-                const rt_material &mat = s.materials[rec.mat];
+                winner_record(s, r, w, rec, want_uv);
                 if (kind == SK_LIGHT) {                               // emitted; scatter = None (material/mod.rs:16-18,174-180)
                     Lterm = rec.front_face ? texture_value(s, mat.tex, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);
                     ended = true;
@@ -400,14 +403,14 @@ RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT>
-__global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & kFeatMisc) ? 4 : 5) wf_trace(const SceneDev *__restrict__ sp, const RenderArgs *__restrict__ ap,
-                                                   const WfPool *__restrict__ pp) {
+__global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & kFeatMisc) ? 4 : 5) wf_trace(const SceneDev s, const WfPool pool,
+                                                   const double t_min, const uint32_t node_quorum_u, StatsDev *stats) {
+    // (Scene and pool by value: pointer members of kernel arguments are known to be global
+    // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
+    // them is re-read from a descriptor in memory inside the traversal loop.)
     __shared__ uint32_t stack_lds[STACK * kBlock];
     __shared__ uint16_t list[S];
     __shared__ uint32_t list_n, list_next;
-    const SceneDev &s = *sp;
-    const RenderArgs &a = *ap;
-    const WfPool &pool = *pp;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
     const uint32_t tid = threadIdx.x;
@@ -438,11 +441,10 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
     TLane L;
     L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
-    L.t_lo = a.t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
+    L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
-    const double t_min = a.t_min;
-    const int node_quorum = (int)a.node_quorum;
+    const int node_quorum = (int)node_quorum_u;
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to.
@@ -660,37 +662,49 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
             }
         }
     }
-    if (STATS) cnt.flush(a.stats);
+    if (STATS) cnt.flush(stats);
 }
 
 // ---- host side of the engine -------------------------------------------------------------
+struct WfLaunch {
+    SceneDev scene;
+    WfPool pool;
+    const RenderArgs *d_args;
+    double t_min;
+    uint32_t node_quorum;
+    StatsDev *stats;
+    uint32_t blocks;
+    hipStream_t stream;
+};
 template <bool STATS>
-static void launch_shade(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((wf_shade<STATS>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+static void launch_shade(const WfLaunch &w) {
+    hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool);
 }
 template <int STACK, bool STATS, unsigned FEAT>
-static void launch_trace(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(blocks), dim3(kBlock), 0, stream, d_scene, d_args, d_pool);
+static void launch_trace(const WfLaunch &w) {
+    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
+                       w.node_quorum, w.stats);
 }
 template <int STACK>
-static void launch_trace_feat(unsigned feat, const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool, uint32_t blocks, hipStream_t stream) {
+static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
     switch (feat & 7u) {
-        case 0: launch_trace<STACK, false, 0>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 1: launch_trace<STACK, false, 1>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 2: launch_trace<STACK, false, 2>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 3: launch_trace<STACK, false, 3>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 4: launch_trace<STACK, false, 4>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 5: launch_trace<STACK, false, 5>(d_scene, d_args, d_pool, blocks, stream); break;
-        case 6: launch_trace<STACK, false, 6>(d_scene, d_args, d_pool, blocks, stream); break;
-        default: launch_trace<STACK, false, 7>(d_scene, d_args, d_pool, blocks, stream); break;
+        case 0: launch_trace<STACK, false, 0>(w); break;
+        case 1: launch_trace<STACK, false, 1>(w); break;
+        case 2: launch_trace<STACK, false, 2>(w); break;
+        case 3: launch_trace<STACK, false, 3>(w); break;
+        case 4: launch_trace<STACK, false, 4>(w); break;
+        case 5: launch_trace<STACK, false, 5>(w); break;
+        case 6: launch_trace<STACK, false, 6>(w); break;
+        default: launch_trace<STACK, false, 7>(w); break;
     }
 }
 
-hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_args, const WfPool *d_pool,
+hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                    uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const uint32_t blocks = pool.n_blocks;
+    const WfLaunch w{scene, pool, d_args, args.t_min, args.node_quorum, args.stats, blocks, stream};
     hipError_t e;
     // Every slot starts FRESH.
     if ((e = hipMemsetAsync(pool.kind, SK_FRESH, pool.n_slots, stream)) != hipSuccess) return e;
@@ -699,14 +713,14 @@ hipError_t launch_render_wavefront(const SceneDev *d_scene, const RenderArgs *d_
     for (;;) {
         for (int k = 0; k < poll_every; k++) {
             if ((e = hipMemsetAsync(pool.n_active, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-            if (counters) launch_shade<true>(d_scene, d_args, d_pool, blocks, stream);
-            else launch_shade<false>(d_scene, d_args, d_pool, blocks, stream);
+            if (counters) launch_shade<true>(w);
+            else launch_shade<false>(w);
             if (stack_need <= (uint32_t)kStackSmall) {
-                if (counters) launch_trace<kStackSmall, true, 7>(d_scene, d_args, d_pool, blocks, stream);
-                else launch_trace_feat<kStackSmall>(features, d_scene, d_args, d_pool, blocks, stream);
+                if (counters) launch_trace<kStackSmall, true, 7>(w);
+                else launch_trace_feat<kStackSmall>(features, w);
             } else {
-                if (counters) launch_trace<kStackLarge, true, 7>(d_scene, d_args, d_pool, blocks, stream);
-                else launch_trace_feat<kStackLarge>(features, d_scene, d_args, d_pool, blocks, stream);
+                if (counters) launch_trace<kStackLarge, true, 7>(w);
+                else launch_trace_feat<kStackLarge>(features, w);
             }
             iterations++;
         }

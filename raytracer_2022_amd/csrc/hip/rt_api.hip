@@ -342,13 +342,11 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         a.tape = nullptr;
         RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
         if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
-        RT_HIP(hipMemcpyAsync(w.d_scene, &sc->dev, sizeof(SceneDev), hipMemcpyHostToDevice, stream));
         RT_HIP(hipMemcpyAsync(w.d_args, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
-        RT_HIP(hipMemcpyAsync(w.d_pool, &w.pool, sizeof(WfPool), hipMemcpyHostToDevice, stream));
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
         RT_HIP(hipEventRecord(w.ev0, stream));
         if (a.n_items > 0) {
-            RT_HIP(launch_render_wavefront(w.d_scene, w.d_args, w.d_pool, w.pool, sc->stack_need, sc->features, counters, w.h_active, stream, &w.iterations));
+            RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.h_active, stream, &w.iterations));
             if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
         RT_HIP(hipEventRecord(w.ev1, stream));

@@ -317,6 +317,8 @@ uint32_t Zoom::flatten(Flattener &f, bool flip) const {
     return push_xform(f, RT_KIND_ZOOM, f.hittable(ptr, false), rate, 0.0, 0.0, flip);
 }
 
+uint32_t FlipFace::flatten(Flattener &f, bool flip) const { return f.hittable(ptr, !flip); }   // mod.rs:281-288
+
 // ------------------------------------------------------------------ BVH ----
 static int box_compare(const HittablePtr &a, const HittablePtr &b, int axis) {    // bvh/mod.rs:19-29
     auto ba = a->bounding_box(0.0, 0.0), bb = b->bounding_box(0.0, 0.0);

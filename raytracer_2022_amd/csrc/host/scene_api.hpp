@@ -250,7 +250,7 @@ struct FlipFace : Hittable {                         // hittable/mod.rs:267-292
     HittablePtr ptr;
     explicit FlipFace(HittablePtr p) : ptr(std::move(p)) {}
     std::optional<AABB> bounding_box(double t0, double t1) const override { return ptr->bounding_box(t0, t1); }
-    uint32_t flatten(Flattener &f, bool flip) const override { return ptr->flatten(f, !flip); }
+    uint32_t flatten(Flattener &f, bool flip) const override;
 };
 
 struct BvhNode : Hittable {                          // hittable/bvh/mod.rs:11-105

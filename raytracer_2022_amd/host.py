@@ -72,7 +72,9 @@ class HostScene:
 
     @property
     def desc(self):
-        return F.lib().rtb_scene_desc(self._h).contents
+        d = F.lib().rtb_scene_desc(self._h).contents
+        d._owner = self          # the pools live inside this scene: keep it alive with the view
+        return d
 
     def default_view(self, aspect_ratio):
         cam = F.rt_camera()

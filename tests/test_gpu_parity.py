@@ -1,0 +1,240 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors. Bar: bit-exact — f64 pixel sums, u8 pixels, ray / node / primitive /
+RNG-draw counters (the last prove that every path took the same branches)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_2022_amd import _ffi as F
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+INDEX = json.load(open(os.path.join(HERE, "golden", "golden_index.json")))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_extension_is_loaded_and_device_visible(rt):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU: the HIP path has no fallback"
+    assert os.path.exists(F.LIB_PATH)
+    s = rt.HostScene("cornell_box")
+    dev = rt.DeviceScene(s.desc)
+    info = dev.info()
+    assert info["stack_need"] >= 1 and info["grid_blocks"] > 0
+
+
+@pytest.mark.parametrize("op,lo,hi", [(0, -1e4, 1e4), (1, -1e4, 1e4), (0, -1e12, 1e12), (2, -1.0, 1.0),
+                                      (4, 0.0, 1.0), (4, 0.0, 1e300), (5, 0.0, 1e6), (5, 0.0, 1e-300)])
+def test_device_math_is_bit_identical_to_host(rt, O, op, lo, hi):
+    """rt_math.h compiled by hipcc for gfx950 == the same header compiled by g++ (sqrt and '/' included)."""
+    x = np.random.default_rng(op + 11).uniform(lo, hi, 300_000)
+    out = np.empty_like(x)
+    F.check(rt.lib().rt_debug_math_device(op, x.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                          out.ctypes.data_as(C.POINTER(C.c_double)), x.size))
+    assert np.array_equal(bits(out), bits(O.math_array(op, x)))
+
+
+@pytest.mark.parametrize("op", [3, 6])
+def test_device_binary_math_is_bit_identical(rt, O, op):
+    rng = np.random.default_rng(5)
+    a, b = rng.uniform(-3, 3, 300_000), rng.uniform(-3, 3, 300_000)
+    out = np.empty_like(a)
+    F.check(rt.lib().rt_debug_math_device(op, a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+                                          out.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+    assert np.array_equal(bits(out), bits(O.math_array(op, a, b)))
+
+
+def test_device_rng_stream_matches_host(rt, O):
+    n = 2048
+    for mode, host in ((0, "u64"), (1, "f64"), (2, "range"), (3, "index")):
+        out = (C.c_uint64 * n)()
+        F.check(rt.lib().rt_debug_rng_device(777, mode, -2.5, 7.25, 11, out, n))
+        if host == "u64":
+            ref = (C.c_uint64 * n)(); O.lib().rto_rng_u64(777, ref, n); ref = np.array(ref[:], dtype=np.uint64)
+        elif host == "f64":
+            ref = (C.c_double * n)(); O.lib().rto_rng_f64(777, ref, n); ref = bits(np.array(ref[:]))
+        elif host == "range":
+            ref = (C.c_double * n)(); O.lib().rto_rng_range(777, -2.5, 7.25, ref, n); ref = bits(np.array(ref[:]))
+        else:
+            ref = (C.c_uint64 * n)(); O.lib().rto_rng_index(777, 11, ref, n); ref = np.array(ref[:], dtype=np.uint64)
+        assert np.array_equal(np.array(out[:], dtype=np.uint64), ref), host
+
+
+def golden_case(name, rt):
+    c = INDEX[name]
+    g = np.load(os.path.join(HERE, "golden", "golden_%s.npz" % name))
+    s = rt.HostScene(c["scene"], seed=c["seed"], param=c["param"])
+    cam, bg = s.default_view(c["width"] / c["height"])
+    p = rt.make_params(c["width"], c["height"], c["spp"], c["max_depth"], bg, seed=c["seed"], n_frames=c["n_frames"],
+                       spp_chunk=c["spp_chunk"])
+    return c, g, s, cam, p
+
+
+@pytest.mark.parametrize("engine", ["wavefront", "mega"])
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_hip_path_reproduces_golden(rt, name, engine):
+    """Every scene builder of the reference (scene.rs) through the kernels, against the committed vectors."""
+    c, g, s, cam, p = golden_case(name, rt)
+    dev = rt.DeviceScene(s.desc)
+    dev.set_engine(engine)
+    out, st = dev.render(cam, p, g["rows"], want_stats=True)
+    assert st.as_dict() == c["counters"], "the device paths took different branches than the oracle's"
+    assert np.array_equal(bits(out), bits(g["rgb_sum"]))
+    assert np.array_equal(rt.write_color(out, c["spp"]), g["rgb8"])
+    # and without counters (the timed kernel variant)
+    out2 = dev.render(cam, p, g["rows"])
+    assert np.array_equal(bits(out2), bits(g["rgb_sum"]))
+
+
+@pytest.mark.parametrize("scene,W,H,spp,chunk,frames", [
+    ("final_scene", 96, 80, 6, 0, 1), ("final_scene", 64, 48, 9, 4, 3), ("cornell_box", 80, 80, 16, 5, 1),
+    ("random_scene", 120, 80, 4, 1, 1), ("cornell_smoke", 64, 64, 6, 0, 2), ("wwscene", 96, 54, 2, 0, 1),
+])
+def test_hip_path_matches_oracle_on_larger_renders(rt, O, scene, W, H, spp, chunk, frames):
+    s = rt.HostScene(scene, seed=31)
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, 50, bg, seed=31, n_frames=frames, spp_chunk=chunk)
+    rows = rt.shuffled_rows(H * frames, 4)
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=os.cpu_count() or 4, want_stats=True)
+    dev = rt.DeviceScene(s.desc)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    assert st.as_dict() == st_ref.as_dict()
+    assert np.array_equal(bits(out), bits(ref))
+    assert np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
+
+
+def test_hand_built_scene_with_every_object_kind(rt, O):
+    """One of each hittable kind (incl. triangle, ring, list, zoom, flipped refs, an image texture, a sphere
+    light) through both engines: the arms no named scene combines."""
+    b = rt.DescBuilder()
+    lam = b.lambertian((0.6, 0.5, 0.4))
+    img = (np.arange(8 * 4 * 3, dtype=np.uint8).reshape(4, 8, 3) * 7) % 251
+    refs = [
+        b.sphere((0, -100, 0), 100.0, b.lambertian(tex=b.checker(b.solid((0.2, 0.3, 0.1)), b.solid((0.9, 0.9, 0.9))))),
+        b.sphere((0, 1, 0), 1.0, b.lambertian(tex=b.image(img))),
+        b.moving_sphere((2.5, 0.5, 0), (2.5, 1.0, 0), 0, 1, 0.5, b.metal((0.8, 0.7, 0.6), 0.3)),
+        b.sphere((-2.5, 1, 0), 1.0, b.dielectric(1.5)),
+        b.triangle((-1, 0.01, 2), (1, 0.01, 2), (0, 1.5, 2.5), lam),
+        b.translate(b.ring(1.5, 0.3, lam), (0, 0.5, -3)),
+        b.translate(b.rotate_y(b.zoom(b.box((-0.5, 0, -0.5), (0.5, 1, 0.5), lam), 1.5), 0.5, 0.8660254037844386), (4.5, 0, 2)),
+        b.medium(b.sphere((-4, 1, 2), 1.0, b.dielectric(1.5)), 0.8, b.isotropic((0.3, 0.3, 0.9))),
+        b.list([b.rect(F.RT_RECT_XZ, -1, 1, -1, 1, 6.0, b.diffuse_light((8, 8, 8)), flip=True),
+                b.rect(F.RT_RECT_XY, -6, 6, 0, 4, -6.0, lam)]),
+    ]
+    light_sphere = b.sphere((5, 6, -2), 0.7, b.diffuse_light((20, 18, 15)))
+    refs.append(light_sphere)
+    b.light(light_sphere)
+    b.light(F.make_ref(F.RT_KIND_RECT, 0))
+    b.set_root(b.list(refs))
+    d = b.desc()
+    W, H, spp = 56, 40, 5
+    cam = rt.camera_new((9, 4, 9), (0, 1, 0), (0, 1, 0), 35.0, W / H, 0.05, 12.0, 0.0, 1.0)
+    p = rt.make_params(W, H, spp, 20, (0.05, 0.06, 0.1), seed=99)
+    rows = np.arange(H, dtype=np.uint32)
+    ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=8, want_stats=True)
+    assert all(st_ref.prim_tests[k] > 0 for k in range(1, F.RT_KIND_COUNT)), "scene does not reach every kind"
+    for engine in ("wavefront", "mega"):
+        dev = rt.DeviceScene(d)
+        dev.set_engine(engine)
+        out, st = dev.render(cam, p, rows, want_stats=True)
+        assert st.as_dict() == st_ref.as_dict(), engine
+        assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(bits(out), bits(ref)), engine
+
+
+def test_edge_cases_empty_and_degenerate(rt, O):
+    s = rt.HostScene("cornell_box")
+    cam, bg = s.default_view(1.0)
+    dev = rt.DeviceScene(s.desc)
+    # no rows
+    out = dev.render(cam, rt.make_params(16, 16, 2, 50, bg), np.zeros(0, dtype=np.uint32))
+    assert out.shape == (0, 16, 3)
+    rows = np.array([3, 3, 0], dtype=np.uint32)                      # a row may be asked twice
+    for spp, depth in ((0, 50), (3, 0), (1, 1)):
+        p = rt.make_params(16, 16, spp, depth, bg, seed=5)
+        ref = O.render_cpu(s.desc, cam, p, rows)
+        got = dev.render(cam, p, rows)
+        assert np.array_equal(bits(got), bits(ref)), (spp, depth)
+        if spp == 0 or depth == 0:
+            assert not got.any()
+    # 1-pixel-wide image: (W-1) == 0 divides to inf/NaN exactly like main.rs:147
+    p = rt.make_params(1, 4, 2, 5, bg, seed=5)
+    r4 = np.arange(4, dtype=np.uint32)
+    a, b2 = dev.render(cam, p, r4), O.render_cpu(s.desc, cam, p, r4)
+    assert np.array_equal(np.isnan(a), np.isnan(b2)) and np.array_equal(bits(a), bits(b2))
+    # a bad row id is an error, not a fault
+    with pytest.raises(rt.RtError):
+        dev.render(cam, rt.make_params(16, 16, 1, 5, bg), np.array([16], dtype=np.uint32))
+
+
+def test_nan_pixels_survive_like_the_reference(rt, O):
+    """pdf_val == 0 -> NaN in the sum -> write_color scrubs the channel (main.rs:266-271, 284-292)."""
+    b = rt.DescBuilder()
+    floor_ = b.rect(F.RT_RECT_XZ, -5, 5, -5, 5, 0.0, b.lambertian((0.7, 0.7, 0.7)))
+    b.set_root(floor_)
+    b.light(b.rect(F.RT_RECT_XZ, -1, 1, -1, 1, -3.0, b.diffuse_light((5, 5, 5))))   # a light below the floor plane
+    d = b.desc()
+    cam = rt.camera_new((0, 3, 6), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    p = rt.make_params(24, 24, 8, 10, (0.2, 0.2, 0.2), seed=3)
+    rows = np.arange(24, dtype=np.uint32)
+    ref = O.render_cpu(d, cam, p, rows)
+    out = rt.DeviceScene(d).render(cam, p, rows)
+    assert np.isnan(ref).any(), "the construction should produce NaN samples"
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    m = ~np.isnan(ref)
+    assert np.array_equal(bits(out[m]), bits(ref[m]))
+    assert np.array_equal(rt.write_color(out, 8), O.write_color(ref, 8))
+
+
+def test_device_buffers_and_tonemap(rt, O):
+    """rt_render_device + rt_tonemap_device with torch-owned HBM buffers on torch's stream."""
+    import torch
+    s = rt.HostScene("final_scene", seed=2022)
+    W = H = 40
+    cam, bg = s.default_view(1.0)
+    p = rt.make_params(W, H, 3, 50, bg, seed=2022)
+    rows = rt.shuffled_rows(H, 1)
+    dev = rt.DeviceScene(s.desc)
+    d_rows = torch.from_numpy(rows.view(np.int32)).cuda()
+    d_out = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
+    d_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    st = F.rt_stats()
+    dev.render_device(cam, p, d_rows.data_ptr(), H, d_out.data_ptr(), stream, st)
+    F.check(rt.lib().rt_tonemap_device(C.c_void_p(d_out.data_ptr()), H * W, 3, C.c_void_p(d_u8.data_ptr()), C.c_void_p(stream)))
+    dev.wait(stream)
+    ref = O.render_cpu(s.desc, cam, p, rows)
+    assert np.array_equal(bits(d_out.cpu().numpy()), bits(ref))
+    assert np.array_equal(d_u8.cpu().numpy(), O.write_color(ref, 3))
+    assert st.ms > 0
+
+
+def test_full_size_properties_of_the_headline_config(rt, O):
+    """At BASELINE's full image size (800x800, book-2 final scene) the oracle cannot render the frame, so:
+    (1) rows rendered separately == rows rendered together (sharding invariance, multi-GPU);
+    (2) re-running gives bit-identical sums (determinism) and both engines agree;
+    (3) a few full-width rows at reduced spp still match the oracle exactly."""
+    W = H = 800
+    s = rt.HostScene("final_scene", seed=2022)
+    cam, bg = s.default_view(1.0)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(W, H, 8, 50, bg, seed=2022, spp_chunk=2)
+    rows = rt.shuffled_rows(H, 2022)
+    full = dev.render(cam, p, rows)
+    again = dev.render(cam, p, rows)
+    assert np.array_equal(bits(full), bits(again))
+    part = dev.render(cam, p, rows[100:164])
+    assert np.array_equal(bits(part), bits(full[100:164]))
+    dev.set_engine("mega")
+    mega = dev.render(cam, p, rows[300:340])
+    assert np.array_equal(bits(mega), bits(full[300:340]))
+    ref = O.render_cpu(s.desc, cam, p, rows[:6], n_threads=6)
+    assert np.array_equal(bits(full[:6]), bits(ref))
+    img = rt.fill_image(full, rows, W, H, 8)
+    assert img.shape == (H, W, 3) and img.max() == 255 and img.mean() > 5
