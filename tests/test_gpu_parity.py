@@ -178,7 +178,9 @@ def test_nan_pixels_survive_like_the_reference(rt, O):
     b = rt.DescBuilder()
     floor_ = b.rect(F.RT_RECT_XZ, -5, 5, -5, 5, 0.0, b.lambertian((0.7, 0.7, 0.7)))
     b.set_root(floor_)
-    b.light(b.rect(F.RT_RECT_XZ, -1, 1, -1, 1, -3.0, b.diffuse_light((5, 5, 5))))   # a light below the floor plane
+    # A FlipFace'd light in the light list answers pdf_value = 0 and random = (1,0,0) (trait defaults,
+    # mod.rs:62-67): along the floor, so cosine = 0, both pdfs 0 and the sample is 0/0.
+    b.light(b.rect(F.RT_RECT_XZ, -1, 1, -1, 1, 3.0, b.diffuse_light((5, 5, 5)), flip=True))
     d = b.desc()
     cam = rt.camera_new((0, 3, 6), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
     p = rt.make_params(24, 24, 8, 10, (0.2, 0.2, 0.2), seed=3)
