@@ -71,13 +71,12 @@ struct WfPool {
     double *ray;            // [P][8]
     // One 32-byte record per slot: {t (f64), leaf ref, box face | movers << 4, 4 mover refs}.
     uint32_t *hit;          // [P][8]
-    uint64_t *item;         // [P]    pixel slot * n_chunks + chunk
-    uint32_t *smp;          // [P]    next sample of the item
-    uint32_t *smp_end;      // [P]
-    uint32_t *depth;        // [P]    remaining depth
-    uint32_t *pix;          // [3][P] px, py, frame of the item
-    double *pixel_sum;      // [3][P]
-    double *tape;           // [max_depth][4][P] bounce records
+    // One 32-byte record per slot: {item = pixel slot * n_chunks + chunk (u64), next sample, end
+    // sample, remaining depth, px, py, frame}.
+    uint32_t *state;        // [P][8]
+    double *pixel_sum;      // [P][4]  running sum of the item (4th double unused)
+    double *tape;           // [P][tape_cap][4] bounce records {w.x, w.y, w.z, p}
+    uint32_t tape_cap;      // records per slot (>= max_depth)
     uint32_t *n_active;     // paths handed to the next trace pass (polled by the host)
 };
 

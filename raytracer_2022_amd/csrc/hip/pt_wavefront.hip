@@ -81,25 +81,52 @@ struct PoolView {
     }
 };
 
-// Bounce tape of one slot (see Tape in pt_kernel.hip): record k, field f at tape[(k*4+f)*P + slot].
+// Bounce tape of one slot (see Tape in pt_kernel.hip): its records are contiguous in HBM,
+// record k = 4 doubles {w.x, w.y, w.z, p} at tape[(slot*cap + k)*4], so unwinding a path reads
+// a few adjacent cache lines; the loads of four records are issued together before use.
 struct SlotTape {
-    double *base;
-    uint64_t P;
-    uint32_t slot;
+    double *base;          // this slot's first record
     RT_DEV void put(uint32_t k, Vec3 w, double p) const {
-        double *q = base + ((uint64_t)k * 4) * P + slot;
-        q[0] = w.x; q[P] = w.y; q[2 * P] = w.z; q[3 * P] = p;
+        double2 *q = reinterpret_cast<double2 *>(base + (uint64_t)k * 4);
+        q[0] = make_double2(w.x, w.y);
+        q[1] = make_double2(w.z, p);
+    }
+    RT_DEV static Vec3 step(Vec3 Lr, double2 a, double2 b) {
+        Vec3 w(a.x, a.y, b.x);
+        return Vec3(0.0, 0.0, 0.0) + (w * Lr) / b.y;           // emitted + ((att*spdf) * L) / pdf_val, main.rs:267-271
     }
     RT_DEV Vec3 unwind(uint32_t nb, Vec3 Lr) const {
-        for (uint32_t k = nb; k > 0; k--) {
-            const double *q = base + ((uint64_t)(k - 1) * 4) * P + slot;
-            Vec3 w(q[0], q[P], q[2 * P]);
-            double p = q[3 * P];
-            Lr = Vec3(0.0, 0.0, 0.0) + (w * Lr) / p;       // emitted + ((att*spdf) * L) / pdf_val, main.rs:267-271
+        const double2 *q = reinterpret_cast<const double2 *>(base);
+        uint32_t k = nb;
+        while (k >= 4) {
+            double2 a3 = q[2 * (k - 1)], b3 = q[2 * (k - 1) + 1], a2 = q[2 * (k - 2)], b2 = q[2 * (k - 2) + 1];
+            double2 a1 = q[2 * (k - 3)], b1 = q[2 * (k - 3) + 1], a0 = q[2 * (k - 4)], b0 = q[2 * (k - 4) + 1];
+            Lr = step(Lr, a3, b3); Lr = step(Lr, a2, b2); Lr = step(Lr, a1, b1); Lr = step(Lr, a0, b0);
+            k -= 4;
         }
+        for (; k > 0; k--) Lr = step(Lr, q[2 * (k - 1)], q[2 * (k - 1) + 1]);
         return Lr;
     }
 };
+
+// Path bookkeeping of one slot, one 32-byte record: {item (u64), smp, smp_end, depth, px, py, frame}.
+struct SlotState {
+    uint64_t item;
+    uint32_t smp, smp_end, depth, px, py, frame;
+};
+RT_DEV SlotState load_state(const WfPool &p, uint32_t slot) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p.state + (uint64_t)slot * 8);
+    uint4 a = q[0], b = q[1];
+    SlotState st;
+    st.item = ((uint64_t)a.y << 32) | a.x;
+    st.smp = a.z; st.smp_end = a.w; st.depth = b.x; st.px = b.y; st.py = b.z; st.frame = b.w;
+    return st;
+}
+RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st) {
+    uint4 *q = reinterpret_cast<uint4 *>(p.state + (uint64_t)slot * 8);
+    q[0] = make_uint4((uint32_t)st.item, (uint32_t)(st.item >> 32), st.smp, st.smp_end);
+    q[1] = make_uint4(st.depth, st.px, st.py, st.frame);
+}
 
 RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
     uint32_t idx = RT_REF_INDEX(leaf);
@@ -169,21 +196,27 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         bool ended = false;          // path ended: add to pixel, start the next sample
         Ray r;
         Rng rng;
-        uint32_t depth = 0;
         Vec3 Lterm(0.0, 0.0, 0.0);
-        SlotTape tape{pool.tape, pool.n_slots, slot};
-
-        if (on && kind >= SK_MISS) {
+        SlotTape tape{pool.tape + (uint64_t)slot * pool.tape_cap * 4};
+        // Everything the slot owns is fetched up front, side by side (the records are independent of
+        // `kind`; a FRESH slot's are stale but mapped), instead of one latency after another.
+        SlotState stt{};
+        Winner w;
+        w.t = 0.0; w.leaf = 0; w.face = 0; w.chain.n = 0; w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
+        if (on) {
             uint64_t rs;
             r = pv.load_ray(slot, rs);
             rng = Rng(rs);
-            depth = pool.depth[slot];
+            stt = load_state(pool, slot);
+            pv.load_hit(slot, w);
+        }
+        uint32_t depth = stt.depth;
+
+        if (on && kind >= SK_MISS) {
             if (kind == SK_MISS) {
                 Lterm = background;                                   // main.rs:275-276
                 ended = true;
             } else {
-                Winner w;
-                pv.load_hit(slot, w);
                 // (u, v) only matter to image textures (and to a checker that may select one).
                 const rt_material &mat = s.materials[leaf_material(s, w.leaf)];
                 bool want_uv = false;
@@ -251,9 +284,10 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             if (ended) {
                 uint32_t nb = a.max_depth - depth;
                 Vec3 Lp = tape.unwind(nb, Lterm);
-                uint64_t P = pool.n_slots;
-                double *ps = pool.pixel_sum + slot;
-                ps[0] = ps[0] + Lp.x; ps[P] = ps[P] + Lp.y; ps[2 * P] = ps[2 * P] + Lp.z;   // pixel_color += ..., main.rs:150
+                double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
+                double2 s0 = ps[0], s1 = ps[1];
+                ps[0] = make_double2(s0.x + Lp.x, s0.y + Lp.y);           // pixel_color += ..., main.rs:150
+                ps[1] = make_double2(s1.x + Lp.z, 0.0);
             }
             cnt.draws(rng.draws);                                     // words drawn while scattering
             rng.draws = 0;
@@ -262,19 +296,16 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         // Next sample of the item, or the next item (main.rs:140-152).
         bool want_path = on && (kind == SK_FRESH || ended);
         if (want_path) {
-            uint64_t P = pool.n_slots;
-            uint32_t smp = 0, smp_end = 0;
             bool have_item = kind != SK_FRESH;
-            if (have_item) { smp = pool.smp[slot]; smp_end = pool.smp_end[slot]; }
+            uint32_t smp = have_item ? stt.smp : 0u, smp_end = have_item ? stt.smp_end : 0u;
             for (int guard = 0; guard < 1 << 20; guard++) {           // loops only through degenerate items (spp or depth 0)
                 bool need = !have_item || smp == smp_end;
                 if (need && have_item) {                              // section_pixel_color.push(pixel_color), main.rs:152
-                    uint64_t item = pool.item[slot];
-                    uint64_t pix_slot = item / a.n_chunks;
-                    uint32_t chunk_id = (uint32_t)(item - pix_slot * a.n_chunks);
+                    uint64_t pix_slot = stt.item / a.n_chunks;
+                    uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
                     double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
-                    const double *ps = pool.pixel_sum + slot;
-                    o[0] = ps[0]; o[1] = ps[P]; o[2] = ps[2 * P];
+                    const double *ps = pool.pixel_sum + (uint64_t)slot * 4;
+                    o[0] = ps[0]; o[1] = ps[1]; o[2] = ps[2];
                     have_item = false;
                 }
                 unsigned long long m = __ballot(need);
@@ -295,17 +326,17 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                             uint32_t py = g - frame * a.height;
                             smp = chunk_id * a.chunk;
                             smp_end = smp + a.chunk < a.spp ? smp + a.chunk : a.spp;
-                            pool.item[slot] = item;
-                            pool.pix[slot] = px; pool.pix[P + slot] = py; pool.pix[2 * P + slot] = frame;
-                            double *ps = pool.pixel_sum + slot;
-                            ps[0] = 0.0; ps[P] = 0.0; ps[2 * P] = 0.0;
+                            stt.item = item; stt.px = px; stt.py = py; stt.frame = frame;
+                            double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
+                            ps[0] = make_double2(0.0, 0.0);
+                            ps[1] = make_double2(0.0, 0.0);
                             have_item = true;
                         }
                     }
                 }
                 if (!have_item) break;                                // no work left: the slot goes idle
                 if (smp == smp_end) continue;                         // empty chunk (spp == 0): store zeros next turn
-                uint32_t px = pool.pix[slot], py = pool.pix[P + slot], frame = pool.pix[2 * P + slot];
+                uint32_t px = stt.px, py = stt.py, frame = stt.frame;
                 uint64_t pixel = (uint64_t)py * a.width + px;
                 rng = Rng(rtm::path_key(a.seed, frame, pixel, smp));  // main.rs:144-149
                 double rand_u = rng.gen_f64();
@@ -322,15 +353,16 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 alive = true;
                 break;
             }
-            pool.smp[slot] = smp;
-            pool.smp_end[slot] = smp_end;
+            stt.smp = smp;
+            stt.smp_end = smp_end;
         }
 
         if (on) {
             if (alive) {
                 cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
                 pv.store_ray(slot, r, rng.s);
-                pool.depth[slot] = depth;
+                stt.depth = depth;
+                store_state(pool, slot, stt);
                 pool.kind[slot] = (uint8_t)SK_TRACE;
                 my_traced++;
             } else {

@@ -284,13 +284,10 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.kind = pool_alloc<uint8_t>(w, P);
     q.ray = pool_alloc<double>(w, 8 * P);
     q.hit = pool_alloc<uint32_t>(w, 8 * P);
-    q.item = pool_alloc<uint64_t>(w, P);
-    q.smp = pool_alloc<uint32_t>(w, P);
-    q.smp_end = pool_alloc<uint32_t>(w, P);
-    q.depth = pool_alloc<uint32_t>(w, P);
-    q.pix = pool_alloc<uint32_t>(w, 3 * P);
-    q.pixel_sum = pool_alloc<double>(w, 3 * P);
+    q.state = pool_alloc<uint32_t>(w, 8 * P);
+    q.pixel_sum = pool_alloc<double>(w, 4 * P);
     q.tape = pool_alloc<double>(w, (uint64_t)depth * 4 * P);
+    q.tape_cap = depth;
     q.n_active = pool_alloc<uint32_t>(w, 1);
     w.pool_slots = slots;
     w.pool_depth = depth;

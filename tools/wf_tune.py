@@ -21,7 +21,7 @@ p0 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
 out, st = dev.render(cam, p0, rows, want_stats=True)
 rays = st.rays
 print('rays', rays, flush=True)
-cfgs = [('wavefront', b, 1, q) for b in (1280,) for q in (6, 10, 14)]
+cfgs = [('wavefront', 1280, 1, q) for q in (10, 14, 18)]
 for eng, blocks, chunk, q in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
