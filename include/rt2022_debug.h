@@ -15,13 +15,19 @@ extern "C" {
 int rt_debug_math_device(int op, const double *a, const double *b, double *out, uint64_t n);
 /* n draws from Rng(state): mode 0 next_u64, 1 gen_f64 (bits), 2 gen_range(lo,hi) (bits), 3 gen_index(bound). */
 int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n);
-/* Scheduler knob of the megakernel: lanes that must want a BVH-node step before the wave
- * takes the node fast path without a vote (1..64). Affects speed only, never results. */
-int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum);
+/* Scheduler knobs of the traversal kernels. node_quorum: lanes that must want a BVH-node step
+ * before the wave takes the node fast path without a vote (1..64). vote_weights: 4 bits per
+ * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label
+ * with the largest lanes * weight. They affect speed only, never results. */
+int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights);
 /* Engine behind rt_render*: 1 (default) = wavefront passes (pt_wavefront.hip), 0 = the single
  * megakernel (pt_kernel.hip). max_pool_blocks: workgroups of 4096 path slots (0 = 4 per CU).
  * Results are bit-identical between the two; only speed differs. */
 int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks);
+/* Scheduler census of the last counter run (RT_FLAG_COUNTERS) of the wavefront traversal kernel:
+ * per operation label (node, sphere, rect, box, medium, misc, ctx, done; [8] = node fast path) the
+ * number of wave-rounds and the lanes they served: lanes / (64 * rounds) = lane utilisation. */
+int rt_debug_census(const rt_scene *scene, uint64_t rounds[9], uint64_t lanes[9]);
 /* Traversal-stack entries the scene needs and the persistent grid size used for it. */
 int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
 

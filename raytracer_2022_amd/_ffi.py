@@ -155,7 +155,7 @@ ABI_SYMBOLS = [
     "rt_tonemap_device", "rt_last_error", "rt_abi_version",
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_last_error", "rtb_abi_sizes",
-    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_set_tuning", "rt_debug_set_engine",
+    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census",
 ]
 
 _lib = None
@@ -199,8 +199,9 @@ def lib():
     L.rt_debug_math_device.argtypes = [C.c_int, P(dbl), P(dbl), P(dbl), u64]
     L.rt_debug_rng_device.argtypes = [u64, C.c_int, dbl, dbl, u64, P(u64), u64]
     L.rt_debug_scene_info.argtypes = [vp, P(u32), P(i32)]
-    L.rt_debug_set_tuning.argtypes = [vp, u32]
+    L.rt_debug_set_tuning.argtypes = [vp, u32, u32]
     L.rt_debug_set_engine.argtypes = [vp, C.c_int, C.c_int]
+    L.rt_debug_census.argtypes = [vp, P(u64), P(u64)]
     _lib = L
     return L
 

@@ -38,6 +38,9 @@ struct StatsDev {
     unsigned long long paths, rays, node_visits;
     unsigned long long prim_tests[RT_KIND_COUNT];
     unsigned long long light_pdf_tests, rng_draws;
+    // Scheduler census of the traversal kernel (counter builds only): per operation label, how many
+    // times a wave ran it and how many lanes it served; [8] = the node fast path.
+    unsigned long long op_rounds[9], op_lanes[9];
 };
 
 struct RenderArgs {
@@ -55,6 +58,7 @@ struct RenderArgs {
     unsigned long long *work_counter;  // zeroed before launch
     double *tape;                      // bounce records: max_depth * 4 doubles per launched lane
     uint32_t node_quorum;              // lanes that must want a node step for the fast path (1..64)
+    uint32_t vote_weights;             // 4 bits per operation label: the vote picks max(lanes * weight)
     StatsDev *stats;                   // may be null
 };
 

@@ -424,11 +424,40 @@ RT_DEV void t_accept(TLane &L, double t, uint32_t face) {
     L.closest = t;
     L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx;
 }
-template <int STACK>
-RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
-    L.top = st.pop(L);
+// L.top has just been set: label it. The two cheap steps of ConstantMedium::hit — start the first
+// boundary query, turn the first into the second (constantmedium.rs:50-51) — are taken on the spot
+// instead of costing the wave a scheduling round each; only the finish (RNG, log) is an operation.
+template <int STACK, bool STATS, unsigned FEAT>
+RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_min, Counters<STATS> &cnt) {
+    if (FEAT & kFeatVolumes) {
+        for (int guard = 0; guard < 6; guard++) {
+            if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM) {               // a medium leaf: boundary.hit(r, -inf, inf)
+                cnt.prim(RT_KIND_MEDIUM);
+                L.med_ref = L.top;
+                L.t_lo = -rtm::INF;
+                L.sub_closest = rtm::INF; L.sub_found = false;
+                st.push(L, REF_MED1);
+                L.top = s.media[RT_REF_INDEX(L.top)].boundary;
+            } else if (L.top == REF_MED1) {
+                if (L.sub_found) {                                    // boundary.hit(r, rec1.t + 0.0001, inf)
+                    L.med_t1 = L.sub_closest;
+                    L.t_lo = L.med_t1 + 0.0001;
+                    L.sub_closest = rtm::INF; L.sub_found = false;
+                    st.push(L, REF_MED2);
+                    L.top = s.media[RT_REF_INDEX(L.med_ref)].boundary;
+                } else {
+                    L.med_ref = 0; L.t_lo = t_min;
+                    L.top = st.pop(L);
+                }
+            } else {
+                break;
+            }
+        }
+    }
     L.op = classify(L.top);
 }
+#define T_NEXT() do { L.top = st.pop(L); t_settle<STACK, STATS, FEAT>(s, L, st, t_min, cnt); } while (0)
+#define T_SETTLE() t_settle<STACK, STATS, FEAT>(s, L, st, t_min, cnt)
 
 } // namespace
 
@@ -436,7 +465,7 @@ RT_DEV void t_next(TLane &L, TStack<STACK> &st) {
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT>
 __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & kFeatMisc) ? 4 : 5) wf_trace(const SceneDev s, const WfPool pool,
-                                                   const double t_min, const uint32_t node_quorum_u, StatsDev *stats) {
+                                                   const double t_min, const uint32_t node_quorum_u, const uint32_t vote_weights, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
@@ -477,6 +506,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
     const int node_quorum = (int)node_quorum_u;
+    unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to.
@@ -484,6 +514,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
             bool isn = L.op == OP_NODE;
             int nn = __popcll(__ballot(isn));
             if (nn < node_quorum) break;
+            if (STATS && lane == 0) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; }
             if (isn) {
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
                 // at once, the right one waits on the stack and is tested against the then-closest hit.
@@ -505,19 +536,18 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                     tmx = t1 < tmx ? t1 : tmx;
                     miss = miss || (tmx <= tmn);
                 }
-                if (!miss) {
-                    // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
-                    // primitive a second time against t_max = its own t finds the same hit again, so
-                    // only the count of tests is kept; anything that can draw from the RNG or carry
-                    // movers (media, movers, nodes, lists) is really visited twice.
-                    uint32_t lk = RT_REF_KIND(left);
-                    if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
-                    else st.push(L, right);
-                    L.top = left;
-                } else {
-                    L.top = st.pop(L);
-                }
-                L.op = classify(L.top);
+                // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
+                // primitive a second time against t_max = its own t finds the same hit again, so
+                // only the count of tests is kept; anything that can draw from the RNG or carry
+                // movers (media, movers, nodes, lists) is really visited twice.
+                const uint32_t lk = RT_REF_KIND(left);
+                const bool twin = left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING;
+                uint32_t next = left;                             // (select, not branch: keeps the child refs' load up front)
+                if (miss) next = st.pop(L);
+                else if (twin) cnt.prim(lk);
+                else st.push(L, right);
+                L.top = next;
+                L.op = classify(next);                            // (media met here start in their own arm)
             }
         }
         // Vote: the label most lanes are waiting on (ties -> lowest id).
@@ -525,9 +555,14 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
 #pragma unroll
         for (int o = 0; o < (int)OP_COUNT; o++) {
             int n = __popcll(__ballot(L.op == (uint32_t)o));
-            if (n > best_n) { best_n = n; best = o; }
+            int score = n * (int)((vote_weights >> (4 * o)) & 0xFu);
+            if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
+        if (STATS) {
+            unsigned served = (unsigned)__popcll(__ballot(L.op == (uint32_t)best));
+            if (lane == 0) { census_rounds[best]++; census_lanes[best] += served; }
+        }
         if (L.op != (uint32_t)best) {
             // parked: this lane's operation did not win the vote
         } else if (best == OP_NODE) {
@@ -550,9 +585,10 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                 if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
                 else st.push(L, right);
                 L.top = left;
-                L.op = classify(L.top);
+                L.op = classify(left);
             } else {
-                t_next(L, st);
+                L.top = st.pop(L);
+                L.op = classify(L.top);
             }
         } else if (best == OP_SPHERE) {                               // Sphere / MovingSphere::hit
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -563,32 +599,22 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
             else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
             double t;
             if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
-            t_next(L, st);
+            T_NEXT();
         } else if (best == OP_RECT) {
             cnt.prim(RT_KIND_RECT);
             const rt_rect &q = s.rects[RT_REF_INDEX(L.top)];
             double t;
             if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, L.cur, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
-            t_next(L, st);
+            T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_BOX) {
             cnt.prim(RT_KIND_BOX);
             double t;
             uint32_t face = 0;
             if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face);
-            t_next(L, st);
+            T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83
-            if (L.top == REF_MED1) {                                  // boundary.hit(r, -inf, inf) is back
-                if (L.sub_found) {
-                    L.med_t1 = L.sub_closest;
-                    L.t_lo = L.med_t1 + 0.0001;                       // boundary.hit(r, rec1.t + 0.0001, inf)
-                    L.sub_closest = rtm::INF; L.sub_found = false;
-                    st.push(L, REF_MED2);
-                    L.top = s.media[RT_REF_INDEX(L.med_ref)].boundary;
-                    L.op = classify(L.top);
-                } else {
-                    L.med_ref = 0; L.t_lo = t_min;
-                    t_next(L, st);
-                }
+            if (L.top != REF_MED2) {
+                T_SETTLE();                                           // a medium leaf or a finished first query: same steps as inline
             } else if (L.top == REF_MED2) {
                 uint32_t mref = L.med_ref;
                 bool both = L.sub_found;
@@ -610,15 +636,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                         }
                     }
                 }
-                t_next(L, st);
-            } else {                                                  // a medium leaf: start its first boundary query
-                cnt.prim(RT_KIND_MEDIUM);
-                L.med_ref = L.top;
-                L.t_lo = -rtm::INF;
-                L.sub_closest = rtm::INF; L.sub_found = false;
-                st.push(L, REF_MED1);
-                L.top = s.media[RT_REF_INDEX(L.top)].boundary;
-                L.op = classify(L.top);
+                T_NEXT();
             }
         } else if ((FEAT & kFeatMisc) && best == OP_MISC) {                                 // Triangle, Ring
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -627,28 +645,28 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
             bool h = kind == RT_KIND_TRIANGLE ? triangle_t(s.triangles[idx], L.cur, L.t_lo, t_hi(L), t)
                                               : ring_t(s.rings[idx], L.cur, L.t_lo, t_hi(L), t);
             if (h) t_accept(L, t, 0);
-            t_next(L, st);
+            T_NEXT();
         } else if ((FEAT & kFeatMovers) && best == OP_CTX) {                                  // movers in / out, HittableList expansion
             if (L.top == REF_POPCTX) {
                 L.ctx.n--;
                 Ray wr = pv.load_ray(L.slot);
                 t_set_cur(L, ray_at_level(s, L.ctx, L.ctx.n, XRay{wr.orig, wr.dir}));
-                t_next(L, st);
+                T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
                 cnt.prim(kind);
                 if (kind == RT_KIND_LIST) {
                     const rt_list &l = s.lists[idx];
                     for (uint32_t i = l.count; i > 0; i--) st.push(L, s.list_items[l.first + i - 1]);
-                    t_next(L, st);
+                    T_NEXT();
                 } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
                     L.ctx.push(L.top);
                     t_set_cur(L, xform_ray(s, L.top, L.cur));
                     st.push(L, REF_POPCTX);
                     L.top = s.xforms[idx].child;
-                    L.op = classify(L.top);
+                    T_SETTLE();
                 } else {
-                    t_next(L, st);
+                    T_NEXT();
                 }
             }
         } else if (best == OP_SHADE) {
@@ -687,14 +705,21 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                 L.ctx.n = 0;
                 L.sp = 0;
                 L.top = s.root;
-                L.op = classify(L.top);
+                T_SETTLE();
                 L.has_ray = true;
             } else {
                 L.op = OP_IDLE;
             }
         }
     }
-    if (STATS) cnt.flush(stats);
+    if (STATS) {
+        cnt.flush(stats);
+        if (lane == 0 && stats)
+            for (int o = 0; o < 9; o++) {
+                if (census_rounds[o]) atomicAdd(&stats->op_rounds[o], (unsigned long long)census_rounds[o]);
+                if (census_lanes[o]) atomicAdd(&stats->op_lanes[o], (unsigned long long)census_lanes[o]);
+            }
+    }
 }
 
 // ---- host side of the engine -------------------------------------------------------------
@@ -704,6 +729,7 @@ struct WfLaunch {
     const RenderArgs *d_args;
     double t_min;
     uint32_t node_quorum;
+    uint32_t vote_weights;
     StatsDev *stats;
     uint32_t blocks;
     hipStream_t stream;
@@ -715,7 +741,7 @@ static void launch_shade(const WfLaunch &w) {
 template <int STACK, bool STATS, unsigned FEAT>
 static void launch_trace(const WfLaunch &w) {
     hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
-                       w.node_quorum, w.stats);
+                       w.node_quorum, w.vote_weights, w.stats);
 }
 template <int STACK>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
@@ -736,7 +762,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                                    uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const uint32_t blocks = pool.n_blocks;
-    const WfLaunch w{scene, pool, d_args, args.t_min, args.node_quorum, args.stats, blocks, stream};
+    const WfLaunch w{scene, pool, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, blocks, stream};
     hipError_t e;
     // Every slot starts FRESH.
     if ((e = hipMemsetAsync(pool.kind, SK_FRESH, pool.n_slots, stream)) != hipSuccess) return e;

@@ -221,8 +221,10 @@ struct rt_scene {
     std::vector<void *> owned;
     uint32_t stack_need = 1;
     unsigned features = 7;
-    uint32_t node_quorum = 12;
+    uint32_t node_quorum = 14;
+    uint32_t vote_weights = 0x11111111u;
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
+    unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
     int max_pool_blocks = 0;          // 0 = 5 x CUs
     int device = 0;
     std::mutex mu;
@@ -326,6 +328,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         a.partial = d_out;
     }
     a.node_quorum = sc->node_quorum;
+    a.vote_weights = sc->vote_weights;
     a.work_counter = w.work_counter;
     a.stats = counters ? w.stats : nullptr;
     if (sc->engine == 1) {
@@ -389,6 +392,10 @@ void finish(rt_scene *sc, hipStream_t stream) {
             out.paths = h.paths; out.rays = h.rays; out.node_visits = h.node_visits;
             for (int k = 0; k < RT_KIND_COUNT; k++) out.prim_tests[k] = h.prim_tests[k];
             out.light_pdf_tests = h.light_pdf_tests; out.rng_draws = h.rng_draws;
+            {
+                std::lock_guard<std::mutex> lock(sc->mu);
+                for (int o = 0; o < 9; o++) { sc->census_rounds[o] = h.op_rounds[o]; sc->census_lanes[o] = h.op_lanes[o]; }
+            }
         }
         float ms = 0.f;
         RT_HIP(hipEventElapsedTime(&ms, w.ev0, w.ev1));
@@ -570,11 +577,13 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
     });
 }
 
-int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum) {
+int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
         RT_REQUIRE(node_quorum >= 1 && node_quorum <= 64, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64");
+        for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
+        scene->vote_weights = vote_weights;
         return RT_OK;
     });
 }
@@ -586,6 +595,14 @@ int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks) {
         RT_REQUIRE(max_pool_blocks >= 0 && max_pool_blocks <= 65535, RT_ERR_INVALID, "rt_debug_set_engine: bad max_pool_blocks");
         scene->engine = engine;
         scene->max_pool_blocks = max_pool_blocks;
+        return RT_OK;
+    });
+}
+
+int rt_debug_census(const rt_scene *scene, uint64_t rounds[9], uint64_t lanes[9]) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene && rounds && lanes, RT_ERR_INVALID, "rt_debug_census: null argument");
+        for (int o = 0; o < 9; o++) { rounds[o] = scene->census_rounds[o]; lanes[o] = scene->census_lanes[o]; }
         return RT_OK;
     });
 }

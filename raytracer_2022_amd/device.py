@@ -18,12 +18,19 @@ class DeviceScene:
         F.check(F.lib().rt_debug_scene_info(self._h, C.byref(need), C.byref(blocks)))
         return {"stack_need": need.value, "grid_blocks": blocks.value}
 
-    def set_tuning(self, node_quorum):
-        F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum))
+    def set_tuning(self, node_quorum, vote_weights=0x11111111):
+        F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))
 
     def set_engine(self, engine, max_pool_blocks=0):
         """engine: "wavefront" (default) or "mega"."""
         F.check(F.lib().rt_debug_set_engine(self._h, {"mega": 0, "wavefront": 1}[engine], max_pool_blocks))
+
+    def census(self):
+        """Scheduler census of the last counter run: {label: (rounds, lanes, utilisation)}."""
+        r, l = (C.c_uint64 * 9)(), (C.c_uint64 * 9)()
+        F.check(F.lib().rt_debug_census(self._h, r, l))
+        names = ["node", "sphere", "rect", "box", "medium", "misc", "ctx", "done", "node_fast"]
+        return {n: (r[i], l[i], (l[i] / (64.0 * r[i])) if r[i] else 0.0) for i, n in enumerate(names)}
 
     def render(self, cam, params, row_ids, want_stats=False):
         """rt_render with host buffers → (n_rows, width, 3) float64 sums [, rt_stats]."""

@@ -21,10 +21,12 @@ p0 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
 out, st = dev.render(cam, p0, rows, want_stats=True)
 rays = st.rays
 print('rays', rays, flush=True)
-cfgs = [('wavefront', 1280, 1, q) for q in (10, 14, 18)]
-for eng, blocks, chunk, q in cfgs:
-    dev.set_engine(eng, blocks); dev.set_tuning(q)
+for k, v in dev.census().items():
+    print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
+cfgs = [('wavefront', 1280, 1, q, w) for q, w in ((14, 0x11111111), (14, 0x22222221), (10, 0x11111111), (18, 0x11111111))]
+for eng, blocks, chunk, q, wts in cfgs:
+    dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
     run(dev, cam, p, rows, W)
     ms = run(dev, cam, p, rows, W)
-    print(f'{eng} blocks={blocks} chunk={chunk} quorum={q}: {ms:.1f} ms  {rays / ms / 1e3:.1f} Mrays/s', flush=True)
+    print(f'{eng} blocks={blocks} chunk={chunk} quorum={q} weights={wts:08x}: {ms:.1f} ms  {rays / ms / 1e3:.1f} Mrays/s', flush=True)
