@@ -505,7 +505,8 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
     L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
-    const int node_quorum = (int)node_quorum_u;
+    const int node_quorum = (int)(node_quorum_u & 0xFFu);
+    const int sphere_reps = (int)((node_quorum_u >> 8) & 0xFu) + 1;
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
@@ -591,15 +592,20 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                 L.op = classify(L.top);
             }
         } else if (best == OP_SPHERE) {                               // Sphere / MovingSphere::hit
-            uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
-            cnt.prim(kind);
-            Vec3 center;
-            double radius;
-            if (kind == RT_KIND_SPHERE) { const rt_sphere &q = s.spheres[idx]; center = ld3(q.center); radius = q.radius; }
-            else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
-            double t;
-            if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
-            T_NEXT();
+            // BVH leaves come in pairs (span-2 nodes): a lane whose next entry is a sphere again takes
+            // it here and now rather than waiting for another round.
+#pragma unroll 1
+            for (int rep = 0; rep < sphere_reps && L.op == OP_SPHERE; rep++) {
+                uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
+                cnt.prim(kind);
+                Vec3 center;
+                double radius;
+                if (kind == RT_KIND_SPHERE) { const rt_sphere &q = s.spheres[idx]; center = ld3(q.center); radius = q.radius; }
+                else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
+                double t;
+                if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
+                T_NEXT();
+            }
         } else if (best == OP_RECT) {
             cnt.prim(RT_KIND_RECT);
             const rt_rect &q = s.rects[RT_REF_INDEX(L.top)];
