@@ -60,6 +60,18 @@ def usable_cores():
     return max(1, n)
 
 
+def measured_traffic(config, spp, spp_chunk):
+    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/r1_hbm_traffic.json), when they
+    were taken on exactly this workload; otherwise None. bench.py cannot run the profiler on itself."""
+    try:
+        t = json.load(open(os.path.join(HERE, "profiles", "r1_hbm_traffic.json")))
+        if t.get("config") == config and t.get("spp") == spp and t.get("spp_chunk") == spp_chunk:
+            return int(t["total_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(scene, cam, params, height, seed, target_s):
     """Time the oracle (the reference's threading scheme) on a bounded sample of the same workload."""
     from oracle import oracle_ffi as O
@@ -200,13 +212,15 @@ def main():
                        "earth_texture": "assets/earthmap.ppm" if assets else "procedural stand-in"},
             "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(args.config, spp, args.spp_chunk) if world == 1 else None,
+                         "traffic_unit": "bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",
                          "kernel": "wf_trace + wf_shade passes of one frame (pt_wavefront.hip)", "kernel_ms": round(k_ms, 3),
                          "algorithmic_bytes_per_launch": int(ab["total"]),
                          "traversal_only": {"bytes": int(ab["traversal"]),
                                             "achieved": round(ab["traversal"] / (k_ms * 1e-3) / 1e9, 2),
                                             "frac": round(ab["traversal"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "note": "scene is L2-resident; ray state lives in registers — see DESIGN.md"},
+                         "note": "170 KB scene is L2-resident, so HBM traffic << algorithmic bytes; the kernel is VALU-issue bound — DESIGN.md §6"},
             "counters_rank0": counts,
         }
         if not args.no_cpu_baseline:

@@ -22,7 +22,7 @@ for kname in ('pt_megakernel', 'wf_trace', 'wf_shade', 'chunk_sum'):
     for f in find('*counter_collection.csv'):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                if kname in row.get('Kernel_Name', '') and 'true>' not in row.get('Kernel_Name', '').replace('Lb1', 'true>'):
+                if kname in row.get('Kernel_Name', '') and ', true' not in row.get('Kernel_Name', '') and '<true' not in row.get('Kernel_Name', ''):
                     tot[row['Counter_Name']] += float(row['Counter_Value']); ndisp[row['Counter_Name']].add(row['Dispatch_Id'])
     if not tot: continue
     print('-- %s (non-counter variant) --' % kname)
@@ -30,9 +30,9 @@ for kname in ('pt_megakernel', 'wf_trace', 'wf_shade', 'chunk_sum'):
         print('%-28s total=%.6g dispatches=%d' % (k, tot[k], len(ndisp[k])))
     g = lambda k: tot.get(k, 0.0)
     if g('SQ_ACTIVE_INST_VALU'):
-        # calibration (tools/calib_util.py): a fully active f64 kernel reads 0.47 in this formula
-        print('lane utilisation raw (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)) = %.3f  (/0.47 calibrated = %.2f)' % (
-            g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64), g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64) / 0.47))
+        # (a fully active streaming kernel — chunk_sum_kernel — reads 1.000 in this formula)
+        print('lane utilisation (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)) = %.3f' % (
+            g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64)))
     if g('FETCH_SIZE') or g('WRITE_SIZE'):
         # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM)
         print('HBM traffic over these dispatches: read %.3f GB (FETCH_SIZE x2), write %.3f GB' % (
