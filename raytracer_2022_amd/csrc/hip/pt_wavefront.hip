@@ -35,11 +35,16 @@ enum SlotKind : uint32_t {
     SK_TRACE = 2,       // carries a ray: world.hit pending
     SK_MISS = 3,
     SK_LIGHT = 4,
-    SK_LAMBERTIAN = 5,
-    SK_METAL = 6,
-    SK_DIELECTRIC = 7,
-    SK_ISOTROPIC = 8,
-    SK_COUNT = 9
+    // Lambertian by albedo texture: a wave that holds one noise-textured hit pays seven octaves of
+    // Perlin for all 64 lanes, so the texture kind is part of the sort key.
+    SK_LAMB_SOLID = 5,
+    SK_LAMB_CHECKER = 6,
+    SK_LAMB_NOISE = 7,
+    SK_LAMB_IMAGE = 8,
+    SK_METAL = 9,
+    SK_DIELECTRIC = 10,
+    SK_ISOTROPIC = 11,
+    SK_COUNT = 12
 };
 
 constexpr int S = kSlotsPerBlock;
@@ -220,7 +225,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 // (u, v) only matter to image textures (and to a checker that may select one).
                 const rt_material &mat = s.materials[leaf_material(s, w.leaf)];
                 bool want_uv = false;
-                if (kind == SK_LIGHT || kind == SK_LAMBERTIAN || kind == SK_ISOTROPIC) {
+                const bool lambertian = kind >= SK_LAMB_SOLID && kind <= SK_LAMB_IMAGE;
+                if (kind == SK_LIGHT || lambertian || kind == SK_ISOTROPIC) {
                     uint32_t tk = s.textures[mat.tex].kind;
                     want_uv = tk == RT_TEX_IMAGE || tk == RT_TEX_CHECKER;
                 }
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     double p = 1.0;
                     Vec3 dir;
                     double tm = r.tm;
-                    if (kind == SK_LAMBERTIAN) {                      // material/mod.rs:51-65 + main.rs:263-271
+                    if (lambertian) {                                 // material/mod.rs:51-65 + main.rs:263-271
                         Vec3 att = texture_value(s, mat.tex, rec.u, rec.v, rec.p);
                         rtm::Onb uvw = rtm::onb_from_w(rec.normal);
                         double cosv;
@@ -684,9 +690,11 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (FEAT & k
                 uint32_t kind = SK_MISS;
                 if (found) {
                     pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4), L.win_chain);
-                    uint32_t mk = s.materials[leaf_material(s, L.win_leaf)].kind;
-                    kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_LAMBERTIAN ? SK_LAMBERTIAN
-                         : mk == RT_MAT_METAL ? SK_METAL : mk == RT_MAT_DIELECTRIC ? SK_DIELECTRIC : SK_ISOTROPIC;
+                    const rt_material &wm = s.materials[leaf_material(s, L.win_leaf)];
+                    uint32_t mk = wm.kind;
+                    kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_METAL ? SK_METAL
+                         : mk == RT_MAT_DIELECTRIC ? SK_DIELECTRIC : mk == RT_MAT_ISOTROPIC ? SK_ISOTROPIC : SK_LAMB_SOLID;
+                    if (mk == RT_MAT_LAMBERTIAN) kind = SK_LAMB_SOLID + s.textures[wm.tex].kind;   // SOLID, CHECKER, NOISE, IMAGE
                 }
                 pool.kind[slot] = (uint8_t)kind;
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
