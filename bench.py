@@ -28,7 +28,10 @@ CONFIGS = {
     "c3": ("final_scene", 800, 800, 1000, "book-2 final scene 800x800x1000spp depth 50"),
     "c2": ("random_scene", 1200, 800, 500, "book-1 final scene (random spheres) 1200x800x500spp depth 50"),
     "c4": ("cornell_box", 600, 600, 1000, "book-3 Cornell box, MixturePdf, 600x600x1000spp depth 50"),
+    # 8-GPU config of BASELINE.json; the mesh is the Shuttle stand-in subdivided to ~1.05 M triangles
+    "c5": ("wwscene", 1920, 1080, 2000, "OBJ mesh scene (~1.05M triangles) + planet textures 1920x1080x2000spp depth 50"),
 }
+SCENE_PARAM = {"c5": 3}
 
 # Algorithmic bytes per unit, SURVEY.md §8(d).
 BYTES_NODE = 64
@@ -142,7 +145,7 @@ def main():
     if args.spp > 0:
         spp = args.spp
     assets = args.assets if os.path.isdir(args.assets) else None
-    scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets)
+    scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
     cam, bg = scene.default_view(W / H)
     params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=world, spp_chunk=args.spp_chunk)
     dscene = rt.DeviceScene(scene.desc)

@@ -86,6 +86,7 @@ struct WfPool {
 
 // Traversal-stack capacities the megakernel is instantiated for.
 constexpr int kStackSmall = 22;   // 22 KiB of stack + 8 KiB ray list: five workgroups fit a CU's 160 KiB of LDS
+constexpr int kStackMid = 30;     // 30 + 8 KiB: four workgroups per CU (million-triangle meshes need ~26 entries)
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
 

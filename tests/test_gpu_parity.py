@@ -148,6 +148,46 @@ def test_hand_built_scene_with_every_object_kind(rt, O):
         assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(bits(out), bits(ref)), engine
 
 
+def test_deep_stacks_select_the_larger_kernels(rt, O):
+    """Traversal-stack variants: 22 entries (default), 30 (million-triangle meshes), 64 (anything deeper)."""
+    # a quarter-million-triangle mesh under three movers: needs the 30-entry stack
+    s = rt.HostScene("wwscene", seed=2022, param=2)
+    dev = rt.DeviceScene(s.desc)
+    assert 22 < dev.info()["stack_need"] <= 30
+    W, H, spp = 64, 36, 2
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, 50, bg, seed=11)
+    rows = rt.shuffled_rows(H, 5)
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=os.cpu_count() or 4, want_stats=True)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    assert st.as_dict() == st_ref.as_dict() and np.array_equal(bits(out), bits(ref))
+    assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref))
+    # a 45-deep left-leaning chain of nodes: needs the 64-entry stack
+    b = rt.DescBuilder()
+    lam = b.lambertian((0.6, 0.6, 0.7))
+    chain = b.sphere((0, 0, -60), 1.0, lam)
+    for i in range(45):
+        chain = b.node((-50, -50, -100), (50, 50, 10), chain, b.sphere((-8 + 0.35 * i, 0.1 * i - 2, -20 - i), 0.8, lam))
+    b.set_root(chain)
+    d = b.desc()
+    dev = rt.DeviceScene(d)
+    assert dev.info()["stack_need"] > 30
+    cam = rt.camera_new((0, 0, 10), (0, 0, -30), (0, 1, 0), 50.0, 1.5, 0.0, 10.0, 0.0, 1.0)
+    p = rt.make_params(48, 32, 3, 20, (0.6, 0.7, 0.9), seed=2)
+    rows = np.arange(32, dtype=np.uint32)
+    ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=4, want_stats=True)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    assert st.as_dict() == st_ref.as_dict() and np.array_equal(bits(out), bits(ref))
+    assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref))
+    # deeper than 64: refused, not truncated
+    for i in range(30):
+        chain = b.node((-50, -50, -100), (50, 50, 10), chain, b.sphere((0, 0, -20), 0.8, lam))
+    b.set_root(chain)
+    with pytest.raises(rt.RtError) as e:
+        rt.DeviceScene(b.desc())
+    assert e.value.code == F.RT_ERR_UNSUPPORTED
+
+
 def test_edge_cases_empty_and_degenerate(rt, O):
     s = rt.HostScene("cornell_box")
     cam, bg = s.default_view(1.0)
