@@ -15,8 +15,10 @@ extern "C" {
 int rt_debug_math_device(int op, const double *a, const double *b, double *out, uint64_t n);
 /* n draws from Rng(state): mode 0 next_u64, 1 gen_f64 (bits), 2 gen_range(lo,hi) (bits), 3 gen_index(bound). */
 int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n);
-/* Scheduler knobs of the traversal kernels. node_quorum: lanes that must want a BVH-node step
- * before the wave takes the node fast path without a vote (1..64). vote_weights: 4 bits per
+/* Scheduler knobs of the traversal kernels. node_quorum: bits 0-7 = lanes that must want a BVH-node
+ * step before the wave takes the node fast path without a vote (1..64); bits 8-11 = extra sphere tests
+ * a lane may take in one turn; bits 20-23 = s: each workgroup's ray list is ordered longest-first by
+ * (node steps of the path's previous ray) >> s, 0 = slot order. vote_weights: 4 bits per
  * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label
  * with the largest lanes * weight. They affect speed only, never results. */
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights);

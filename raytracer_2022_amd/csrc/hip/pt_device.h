@@ -81,6 +81,7 @@ struct WfPool {
     double *pixel_sum;      // [P][4]  running sum of the item (4th double unused)
     double *tape;           // [P][tape_cap][4] bounce records {w.x, w.y, w.z, p}
     uint32_t tape_cap;      // records per slot (>= max_depth)
+    uint16_t *prev_steps;   // [P] node steps of the slot's previous ray (0 for a camera ray): long-first ordering
     uint32_t *n_active;     // paths handed to the next trace pass (polled by the host)
 };
 

@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 double u = ((double)px + rand_u) / (double)(a.width - 1);
                 double v = ((double)py + rand_v) / (double)(a.height - 1);
                 r = get_ray(a.cam, u, v, rng);
+                pool.prev_steps[slot] = 0;
                 depth = a.max_depth;
                 smp++;
                 cnt.path();
@@ -407,6 +408,7 @@ struct TLane {
     Chain win_chain;
     uint32_t win_leaf, win_face;
     uint32_t slot;
+    uint32_t steps;        // node steps of this ray
     int sp;
     uint32_t top, op;
     bool has_ray;
@@ -478,6 +480,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     __shared__ uint32_t stack_lds[STACK * kBlock];
     __shared__ uint16_t list[S];
     __shared__ uint32_t list_n, list_next;
+    __shared__ uint32_t bins[16];
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
     const uint32_t tid = threadIdx.x;
@@ -487,26 +490,40 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
 
     if (tid == 0) { list_n = 0; list_next = 0; }
     __syncthreads();
-    // Compact the slots that carry a ray (wave-level: one LDS atomic per wave and pass).
+    // Compact the slots that carry a ray into the list, longest expected traversal first (counting sort
+    // on the node steps of the path's previous ray, 16 classes): the stragglers of this pass then start
+    // early instead of keeping a few lanes busy after the list has run dry.
+    const uint32_t step_shift = (node_quorum_u >> 20) & 0xFu;        // class = steps >> shift (0 = plain slot order)
+    if (tid < 16) { bins[tid] = 0; }
+    __syncthreads();
+    uint32_t my_key[S / kBlock];
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t local = (uint32_t)(i * kBlock) + tid;
-        bool pending = pool.kind[base + local] == SK_TRACE;
-        unsigned long long m = __ballot(pending);
-        if (m) {
-            int leader = __ffsll((long long)m) - 1;
-            uint32_t wbase = 0;
-            if ((int)lane == leader) wbase = atomicAdd(&list_n, (uint32_t)__popcll(m));
-            wbase = __shfl(wbase, leader);
-            if (pending) list[wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)local;
+        uint32_t key = 16;                                             // not pending
+        if (pool.kind[base + local] == SK_TRACE) {
+            uint32_t cls = step_shift ? ((uint32_t)pool.prev_steps[base + local] >> step_shift) : 0u;
+            key = 15u - (cls > 15u ? 15u : cls);
+            atomicAdd(&bins[key], 1u);
         }
+        my_key[i] = key;
     }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 16; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
+        list_n = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++)
+        if (my_key[i] < 16) list[atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
     __syncthreads();
     const uint32_t n_list = list_n;
     if (n_list == 0) return;
 
     TLane L;
-    L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0;
+    L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
     L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
@@ -526,6 +543,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
                 // at once, the right one waits on the stack and is tested against the then-closest hit.
                 cnt.node();
+                L.steps++;
                 const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + RT_REF_INDEX(L.top));
                 uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 double bmin[3] = {rtm::u2d(((uint64_t)q0.y << 32) | q0.x), rtm::u2d(((uint64_t)q0.w << 32) | q0.z), rtm::u2d(((uint64_t)q1.y << 32) | q1.x)};
@@ -574,6 +592,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             // parked: this lane's operation did not win the vote
         } else if (best == OP_NODE) {
             cnt.node();
+            L.steps++;
             const rt_bvh_node &n = s.nodes[RT_REF_INDEX(L.top)];
             double tmn = L.t_lo, tmx = t_hi(L);
             bool miss = false;
@@ -697,6 +716,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                     if (mk == RT_MAT_LAMBERTIAN) kind = SK_LAMB_SOLID + s.textures[wm.tex].kind;   // SOLID, CHECKER, NOISE, IMAGE
                 }
                 pool.kind[slot] = (uint8_t)kind;
+                pool.prev_steps[slot] = (uint16_t)(L.steps > 0xFFFFu ? 0xFFFFu : L.steps);
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
@@ -714,6 +734,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir});
                 L.closest = rtm::F64_MAX;
+                L.steps = 0;
                 L.t_lo = t_min; L.med_ref = 0;
                 L.win_leaf = REF_EMPTY; L.win_face = 0;
                 L.ctx.n = 0;

@@ -221,7 +221,7 @@ struct rt_scene {
     std::vector<void *> owned;
     uint32_t stack_need = 1;
     unsigned features = 7;
-    uint32_t node_quorum = 14u | (1u << 8);   // fast-path quorum 14 lanes; one extra sphere test per turn
+    uint32_t node_quorum = 14u | (1u << 8) | (2u << 20);   // fast-path quorum 14 lanes; one extra sphere test per turn; long-first classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
@@ -290,6 +290,7 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.pixel_sum = pool_alloc<double>(w, 4 * P);
     q.tape = pool_alloc<double>(w, (uint64_t)depth * 4 * P);
     q.tape_cap = depth;
+    q.prev_steps = pool_alloc<uint16_t>(w, P);
     q.n_active = pool_alloc<uint32_t>(w, 1);
     w.pool_slots = slots;
     w.pool_depth = depth;
@@ -580,7 +581,7 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
-        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && node_quorum < 0x1000u, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8)");
+        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + long-first class shift << 20)");
         for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
         scene->vote_weights = vote_weights;

@@ -23,7 +23,7 @@ rays = st.rays
 print('rays', rays, flush=True)
 for k, v in dev.census().items():
     print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
-cfgs = [('wavefront', 1280, 1, 14 + 0x100, 0x22222221)]
+cfgs = [('wavefront', 1280, 1, 14 + 0x100 + (t << 20), 0x22222221) for t in (0, 2, 3, 4)]
 for eng, blocks, chunk, q, wts in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
