@@ -125,9 +125,10 @@ typedef struct rt_ring {              /* 40 B */
 } rt_ring;
 
 /* ConstantMedium{boundary, phase_function: Isotropic, neg_inv_density}. 16 B.
- * `mat` must be an RT_MAT_ISOTROPIC material. Device path: the boundary may be
- * any primitive (SPHERE..RING) under up to RT_MAX_XFORM_DEPTH movers — every
- * boundary the reference builds (scene.rs:230-254, 316-329) is of that form. */
+ * `mat` must be an RT_MAT_ISOTROPIC material. Device path: the boundary must be a
+ * primitive (SPHERE..RING) under up to RT_MAX_XFORM_DEPTH movers — every boundary
+ * the reference builds (scene.rs:230-254, 316-329) is of that form; anything else
+ * is refused with RT_ERR_UNSUPPORTED. */
 typedef struct rt_medium {
     uint32_t boundary;
     uint32_t mat;
@@ -291,9 +292,13 @@ int rt_scene_destroy(rt_scene *scene);
 int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
               double *out_rgb_sum, rt_stats *stats);
 
-/* Same, with params->row_ids and d_out_rgb_sum resident in HBM and the work
- * enqueued on `hip_stream` (a hipStream_t; NULL = default stream). Returns
- * after enqueueing; `stats`, if given, is filled at the next rt_render_wait. */
+/* Same, with params->row_ids and d_out_rgb_sum resident in HBM and every launch
+ * issued on `hip_stream` (a hipStream_t; NULL = default stream), so it orders with
+ * the caller's other work on that stream. The default engine drives its passes
+ * from the host and polls a completion word, so the call returns when the frame's
+ * last pass has been issued and observed (it synchronises `hip_stream`); `stats`,
+ * if given, is filled by the next rt_render_wait on the same stream. One host
+ * thread per (scene, stream). */
 int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                      double *d_out_rgb_sum, void *hip_stream, rt_stats *stats);
 int rt_render_wait(rt_scene *scene, void *hip_stream);
