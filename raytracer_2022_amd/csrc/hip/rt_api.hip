@@ -221,7 +221,7 @@ struct rt_scene {
     std::vector<void *> owned;
     uint32_t stack_need = 1;
     unsigned features = 7;
-    uint32_t node_quorum = 14u | (1u << 8) | (2u << 20);   // fast-path quorum 14 lanes; one extra sphere test per turn; long-first classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; long-first classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
