@@ -125,10 +125,10 @@ typedef struct rt_ring {              /* 40 B */
 } rt_ring;
 
 /* ConstantMedium{boundary, phase_function: Isotropic, neg_inv_density}. 16 B.
- * `mat` must be an RT_MAT_ISOTROPIC material. Device path: the boundary must be a
- * primitive (SPHERE..RING) under up to RT_MAX_XFORM_DEPTH movers — every boundary
- * the reference builds (scene.rs:230-254, 316-329) is of that form; anything else
- * is refused with RT_ERR_UNSUPPORTED. */
+ * `mat` must be an RT_MAT_ISOTROPIC material. The boundary may be any hittable
+ * that contains no further medium (the reference's are a Sphere and
+ * Translate<RotateY<Boxes>>, scene.rs:230-254, 316-329); a medium nested inside a
+ * boundary is refused with RT_ERR_UNSUPPORTED. */
 typedef struct rt_medium {
     uint32_t boundary;
     uint32_t mat;

@@ -43,6 +43,8 @@ struct Validator {
     const rt_scene_desc &d;
     std::vector<int32_t> node_need;      // memo: stack need of each node (-1 unknown, -2 on the DFS stack)
     std::vector<int32_t> node_xdepth;
+    mutable bool general_boundaries = false;   // some medium boundary is more than a primitive under movers
+    bool in_boundary = false;                  // need(): inside a medium's boundary (media do not nest there)
     explicit Validator(const rt_scene_desc &desc) : d(desc), node_need(desc.n_nodes, -1), node_xdepth(desc.n_nodes, 0) {}
 
     uint32_t pool_size(uint32_t kind) const {
@@ -90,17 +92,19 @@ struct Validator {
             check_mat(d.media[i].mat, "medium");
             RT_REQUIRE(d.materials[d.media[i].mat].kind == RT_MAT_ISOTROPIC, RT_ERR_INVALID, "medium: phase function must be Isotropic");
             check_ref(d.media[i].boundary, "medium.boundary");
-            // Device path: movers around one primitive (see rt_medium in rt2022.h).
+            // A boundary that is one primitive under movers is what the megakernel engine handles;
+            // anything else (a box of boxes, a BVH, a list) needs the wavefront engine's sub-queries.
             uint32_t ref = d.media[i].boundary;
             int lvl = 0;
+            bool simple = true;
             while (RT_REF_KIND(ref) >= RT_KIND_TRANSLATE && RT_REF_KIND(ref) <= RT_KIND_ZOOM) {
-                RT_REQUIRE(++lvl <= RT_MAX_XFORM_DEPTH, RT_ERR_UNSUPPORTED, "medium: boundary nested under too many movers");
+                if (++lvl > RT_MAX_XFORM_DEPTH) { simple = false; break; }
                 ref = d.xforms[RT_REF_INDEX(ref)].child;
                 check_ref(ref, "medium.boundary chain");
             }
             uint32_t k = RT_REF_KIND(ref);
-            RT_REQUIRE(k >= RT_KIND_SPHERE && k <= RT_KIND_RING, RT_ERR_UNSUPPORTED,
-                       "medium: boundary must be a primitive, optionally under movers");
+            if (!(k >= RT_KIND_SPHERE && k <= RT_KIND_RING)) simple = false;
+            if (!simple) general_boundaries = true;
         }
         for (uint32_t i = 0; i < d.n_xforms; i++) {
             uint32_t k = d.xforms[i].kind;
@@ -176,6 +180,17 @@ struct Validator {
             out_xdepth = bx;
             return;
         }
+        if (kind == RT_KIND_MEDIUM) {
+            // the medium's own slot becomes the sub-query sentinel while its boundary is traversed
+            RT_REQUIRE(!in_boundary, RT_ERR_UNSUPPORTED, "a medium inside another medium's boundary");
+            in_boundary = true;
+            int32_t nb, xb;
+            need(d.media[idx].boundary, depth + 1, nb, xb);
+            in_boundary = false;
+            out_need = 1 + nb;
+            out_xdepth = xb;
+            return;
+        }
         out_need = 1;
         out_xdepth = 0;
     }
@@ -221,6 +236,7 @@ struct rt_scene {
     std::vector<void *> owned;
     uint32_t stack_need = 1;
     unsigned features = 7;
+    bool general_boundaries = false;
     uint32_t node_quorum = 18u | (1u << 8) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; long-first classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
@@ -448,6 +464,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.root = desc->root;
             s.n_lights = desc->n_lights;
             sc->stack_need = (uint32_t)need;
+            sc->general_boundaries = v.general_boundaries;
             sc->features = ((desc->n_triangles || desc->n_rings) ? kFeatMisc : 0u) |
                            ((desc->n_xforms || desc->n_lists) ? kFeatMovers : 0u) |
                            ((desc->n_boxes || desc->n_media) ? kFeatVolumes : 0u);
@@ -594,6 +611,8 @@ int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks) {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_engine: null scene");
         RT_REQUIRE(engine == 0 || engine == 1, RT_ERR_INVALID, "rt_debug_set_engine: engine must be 0 (megakernel) or 1 (wavefront)");
         RT_REQUIRE(max_pool_blocks >= 0 && max_pool_blocks <= 65535, RT_ERR_INVALID, "rt_debug_set_engine: bad max_pool_blocks");
+        RT_REQUIRE(engine == 1 || !scene->general_boundaries, RT_ERR_UNSUPPORTED,
+                   "the megakernel engine only handles media whose boundary is one primitive under movers");
         scene->engine = engine;
         scene->max_pool_blocks = max_pool_blocks;
         return RT_OK;

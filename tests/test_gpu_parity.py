@@ -188,6 +188,40 @@ def test_deep_stacks_select_the_larger_kernels(rt, O):
     assert e.value.code == F.RT_ERR_UNSUPPORTED
 
 
+def test_medium_with_a_composite_boundary(rt, O):
+    """ConstantMedium<H> for any H (constantmedium.rs:14-22): a boundary that is a BVH of a box and a sphere.
+    The two boundary queries run through the ordinary traversal arms with their own t window."""
+    b = rt.DescBuilder()
+    glass = b.dielectric(1.5)
+    shell = b.node((-3, -3, -8), (3, 3, -2), b.box((-2, -1, -7), (0.5, 1, -4), glass), b.sphere((1.0, 0, -5), 1.5, glass))
+    fog = b.medium(shell, 0.9, b.isotropic((0.8, 0.5, 0.3)))
+    floor_ = b.rect(F.RT_RECT_XZ, -20, 20, -20, 20, -1.5, b.lambertian((0.5, 0.5, 0.5)))
+    light = b.rect(F.RT_RECT_XZ, -2, 2, -7, -3, 6.0, b.diffuse_light((9, 9, 9)), flip=True)
+    b.set_root(b.list([fog, floor_, light]))
+    b.light(F.make_ref(F.RT_KIND_RECT, 1))
+    d = b.desc()
+    W, H, spp = 48, 36, 6
+    cam = rt.camera_new((0, 1, 4), (0, 0, -5), (0, 1, 0), 45.0, W / H, 0.0, 9.0, 0.0, 1.0)
+    p = rt.make_params(W, H, spp, 30, (0.1, 0.1, 0.15), seed=8)
+    rows = np.arange(H, dtype=np.uint32)
+    ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=8, want_stats=True)
+    assert st_ref.prim_tests[F.RT_KIND_MEDIUM] > 0 and st_ref.prim_tests[F.RT_KIND_BOX] > 0
+    dev = rt.DeviceScene(d)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    assert st.as_dict() == st_ref.as_dict()
+    assert np.array_equal(bits(out), bits(ref))
+    with pytest.raises(rt.RtError) as e:                      # the A/B megakernel cannot take this scene
+        dev.set_engine("mega")
+    assert e.value.code == F.RT_ERR_UNSUPPORTED
+    # media do not nest inside a boundary
+    b2 = rt.DescBuilder()
+    inner = b2.medium(b2.sphere((0, 0, 0), 1.0, b2.dielectric(1.5)), 0.5, b2.isotropic((1, 1, 1)))
+    b2.set_root(b2.medium(inner, 0.5, b2.isotropic((1, 1, 1))))
+    with pytest.raises(rt.RtError) as e:
+        rt.DeviceScene(b2.desc())
+    assert e.value.code == F.RT_ERR_UNSUPPORTED
+
+
 def test_edge_cases_empty_and_degenerate(rt, O):
     s = rt.HostScene("cornell_box")
     cam, bg = s.default_view(1.0)
