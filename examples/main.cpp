@@ -1,0 +1,93 @@
+// examples/main.cpp — the reference's main() (raytracer/src/main.rs:28-231) over this library:
+// constants, Camera::new, scene, BvhNode::new_list, shuffled rows, render, write_color + image fill,
+// image file. The render threads of main.rs:109-183 become one rt_render call on the GPU.
+//
+//   make -C examples && ./examples/render final_scene 400 400 100 out.ppm
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../include/rt2022.h"
+#include "../include/rt2022_host.h"
+#include "../raytracer_2022_amd/csrc/host/scene_api.hpp"
+
+using namespace rt2022;
+
+int main(int argc, char **argv) {
+    // Image (main.rs:33-41)
+    const std::string scene_name = argc > 1 ? argv[1] : "cornell_box";
+    const uint32_t IMAGE_WIDTH = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 600;
+    const uint32_t IMAGE_HEIGHT = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 600;
+    const uint32_t SAMPLES_PER_PIXEL = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 100;
+    const std::string path = argc > 5 ? argv[5] : "output.ppm";
+    const uint32_t MAX_DEPTH = 50;
+    const double ASPECT_RATIO = (double)IMAGE_WIDTH / (double)IMAGE_HEIGHT;
+    const uint64_t SEED = 2022;          // the reference draws from thread_rng(); a seed is required here
+
+    auto begin_time = std::chrono::steady_clock::now();
+    std::printf("[1/5] Initlizing...\nIMAGE SIZE: %ux%u\nSAMPLE PER PIXEL: %u\nMAX DEPTH: %u\n", IMAGE_WIDTH, IMAGE_HEIGHT,
+                SAMPLES_PER_PIXEL, MAX_DEPTH);
+
+    try {
+        HostRng rng(SEED);
+        // World & lights (main.rs:89-90) through the C++ mirror of scene.rs
+        SceneOut sc;
+        Color background(0.0, 0.0, 0.0);
+        Point3 lookfrom(278.0, 278.0, -800.0), lookat(278.0, 278.0, 0.0);
+        Vec3 vup(0.0, 1.0, 0.0);
+        double vfov = 40.0, aperture = 0.0, focus_dist = 10.0, time0 = 0.0, time1 = 1.0;
+        if (scene_name == "cornell_box") sc = cornell_box(rng);
+        else if (scene_name == "cornell_smoke") sc = cornell_smoke(rng);
+        else if (scene_name == "final_scene") { sc = final_scene(rng, SceneAssets{"assets"}); lookfrom = Point3(478.0, 278.0, -600.0); }
+        else if (scene_name == "random_scene") {
+            sc = random_scene(rng);
+            lookfrom = Point3(13.0, 2.0, 3.0); lookat = Point3(0.0, 0.0, 0.0); vfov = 20.0; aperture = 0.1;
+            background = Color(0.7, 0.8, 1.0);
+        } else if (scene_name == "wwscene") {                    // the camera of main.rs:43-51
+            sc = wwscene(rng, SceneAssets{"assets"}, 0);
+            vup = Vec3(1.0, 5.0, 0.0); lookfrom = Point3(0.0, 15.0, -150.0); lookat = Point3(35.0, 0.0, 0.0);
+        } else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
+
+        Camera cam(lookfrom, lookat, vup, vfov, ASPECT_RATIO, aperture, focus_dist, time0, time1);   // main.rs:68-78
+        auto main_world = BvhNode::new_list(sc.world, time0, time1, rng);                            // main.rs:90
+        std::vector<uint32_t> random_line_id = shuffled_rows(IMAGE_HEIGHT, rng);                     // main.rs:93-99
+
+        Flattener flat;
+        flat.set_world(main_world);
+        flat.set_lights(sc.lights);
+        rt_scene_desc desc = flat.desc();
+
+        std::printf("[2/5] Rendering on the GPU...\n");
+        rt_scene *scene = nullptr;
+        if (rt_scene_create(&desc, &scene) != RT_OK) { std::fprintf(stderr, "rt_scene_create: %s\n", rt_last_error()); return 1; }
+        rt_params p{};
+        p.width = IMAGE_WIDTH; p.height = IMAGE_HEIGHT; p.spp = SAMPLES_PER_PIXEL; p.max_depth = MAX_DEPTH;
+        p.background[0] = background.x; p.background[1] = background.y; p.background[2] = background.z;
+        p.t_min = 0.001; p.seed = SEED; p.n_frames = 1;
+        p.n_rows = IMAGE_HEIGHT; p.row_ids = random_line_id.data();
+        p.spp_chunk = 0; p.flags = 0;
+        std::vector<double> output_pixel_color((size_t)IMAGE_WIDTH * IMAGE_HEIGHT * 3);
+        rt_stats stats{};
+        if (rt_render(scene, &cam.c, &p, output_pixel_color.data(), &stats) != RT_OK) {
+            std::fprintf(stderr, "rt_render: %s\n", rt_last_error());
+            return 1;
+        }
+        std::printf("[3/5] Collecting Results... (%.1f ms on the device)\n", stats.ms);
+
+        std::printf("[4/5] Generating Image...\n");                                                  // main.rs:191-201
+        std::vector<uint8_t> img((size_t)IMAGE_WIDTH * IMAGE_HEIGHT * 3);
+        rtb_fill_image(output_pixel_color.data(), random_line_id.data(), IMAGE_HEIGHT, IMAGE_WIDTH, IMAGE_HEIGHT,
+                       (int32_t)SAMPLES_PER_PIXEL, img.data());
+        std::printf("[5/5] Outping Image...\nOuput image as \"%s\"\n", path.c_str());
+        if (rtb_write_ppm(path.c_str(), img.data(), IMAGE_WIDTH, IMAGE_HEIGHT) != RT_OK) std::printf("Outputting image fails.\n");
+        rt_scene_destroy(scene);
+    } catch (const Error &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - begin_time).count();
+    std::printf("\n      All Work Done.\n      Elapsed Time: %.2f s\n\n", secs);
+    return 0;
+}
