@@ -757,6 +757,13 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     }
 }
 
+// Marks the first `used` slots of every workgroup FRESH and the rest IDLE: a small job is spread
+// over all workgroups (a few slots each) instead of filling a few workgroups to the brim.
+__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint32_t n_slots, uint32_t used) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots) kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE;
+}
+
 // ---- host side of the engine -------------------------------------------------------------
 struct WfLaunch {
     SceneDev scene;
@@ -799,8 +806,15 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
     const uint32_t blocks = pool.n_blocks;
     const WfLaunch w{scene, pool, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, blocks, stream};
     hipError_t e;
-    // Every slot starts FRESH.
-    if ((e = hipMemsetAsync(pool.kind, SK_FRESH, pool.n_slots, stream)) != hipSuccess) return e;
+    // Slots in use start FRESH (at most one work item per slot is ever needed at a time).
+    {
+        uint64_t per_block = (args.n_items + blocks - 1) / blocks;
+        uint32_t used = (uint32_t)(per_block > (uint64_t)S ? (uint64_t)S : (per_block + 63) / 64 * 64);
+        if (used < 64) used = 64;
+        uint32_t n = blocks * (uint32_t)S;
+        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, n, used);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     uint32_t iterations = 0;
     const int poll_every = 4;
     for (;;) {

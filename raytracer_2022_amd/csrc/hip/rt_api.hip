@@ -353,7 +353,8 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         hipDeviceProp_t prop;
         RT_HIP(hipGetDeviceProperties(&prop, sc->device));
         uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 5u * (uint32_t)prop.multiProcessorCount;
-        uint64_t want = (a.n_items + kSlotsPerBlock - 1) / kSlotsPerBlock;
+        // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
+        uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
         ensure_pool(w, blocks, p->max_depth, stream);
         a.tape = nullptr;
