@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __shared__ uint32_t cursor[SK_COUNT];
     __shared__ uint32_t sorted[S];
     __shared__ uint32_t n_sorted, n_traced;
+    __shared__ uint8_t new_kind[S];      // the slots' next state, written back in one coalesced sweep
     const RenderArgs &a = *ap;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t k = pool.kind[base + i * kBlock + tid];
         my_kind[i] = k;
+        new_kind[i * kBlock + tid] = (uint8_t)SK_IDLE;
         if (k != SK_IDLE) atomicAdd(&hist[k], 1u);
     }
     __syncthreads();
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t k = my_kind[i];
-        if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = (uint32_t)(i * kBlock) + tid;
+        if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = ((uint32_t)(i * kBlock) + tid) | (k << 16);
     }
     __syncthreads();
     const uint32_t total = n_sorted;
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         const uint32_t j = j0 + tid;
         const bool on = j < total;
         uint32_t slot = 0, kind = SK_IDLE;
-        if (on) { slot = base + sorted[j]; kind = pool.kind[slot]; }
+        if (on) { uint32_t e = sorted[j]; slot = base + (e & 0xFFFFu); kind = e >> 16; }
         bool alive = false;          // path continues with a new ray
         bool ended = false;          // path ended: add to pixel, start the next sample
         Ray r;
@@ -370,16 +372,19 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 pv.store_ray(slot, r, rng.s);
                 stt.depth = depth;
                 store_state(pool, slot, stt);
-                pool.kind[slot] = (uint8_t)SK_TRACE;
+                new_kind[slot - base] = (uint8_t)SK_TRACE;
                 my_traced++;
-            } else {
-                pool.kind[slot] = (uint8_t)SK_IDLE;
             }
         }
     }
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
     if (my_traced) atomicAdd(&n_traced, my_traced);
     __syncthreads();
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(new_kind);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(pool.kind + base);
+        for (uint32_t i = tid; i < (uint32_t)S / 4; i += kBlock) dst[i] = src[i];
+    }
     if (tid == 0 && n_traced) atomicAdd(pool.n_active, n_traced);
     if (STATS) cnt.flush(a.stats);
 }

@@ -24,7 +24,7 @@ rays = st.rays
 print('rays', rays, flush=True)
 for k, v in dev.census().items():
     print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
-cfgs = [('wavefront', 1280, 1, q + 0x100 + (2 << 20), w) for q, w in ((14, 0x22222221), (10, 0x22222221), (18, 0x22222221), (24, 0x22222221), (14, 0x11111111), (14, 0x22221221))] + [('wavefront', 1280, 1, 14 + 0x200 + (2 << 20), 0x22222221)]
+cfgs = [('wavefront', 1280, 1, 18 + 0x100 + (2 << 20), 0x22222221)] * 2
 for eng, blocks, chunk, q, wts in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
