@@ -66,6 +66,7 @@ struct Counters<false> {
     RT_DEV void light_pdf() {}
     RT_DEV void draws(uint32_t) {}
     RT_DEV void flush(StatsDev *) {}
+    RT_DEV void flush_wave(StatsDev *) {}
 };
 template <>
 struct Counters<true> {
@@ -90,6 +91,27 @@ struct Counters<true> {
 #pragma unroll
         for (int i = 0; i < RT_KIND_COUNT; i++)
             if (prims[i]) atomicAdd(&st->prim_tests[i], (unsigned long long)prims[i]);
+        paths = rays = nodes = lpdf = ndraws = 0;
+#pragma unroll
+        for (int i = 0; i < RT_KIND_COUNT; i++) prims[i] = 0;
+    }
+    // Same, from a point every lane of the wave reaches together: one atomic per wave and counter.
+    RT_DEV static unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        return v;
+    }
+    RT_DEV void flush_wave(StatsDev *st) {
+        if (!st) return;
+        const bool first = (threadIdx.x & 63u) == 0;
+        unsigned long long v;
+        v = wave_sum(paths); if (first && v) atomicAdd(&st->paths, v);
+        v = wave_sum(rays); if (first && v) atomicAdd(&st->rays, v);
+        v = wave_sum(nodes); if (first && v) atomicAdd(&st->node_visits, v);
+        v = wave_sum(lpdf); if (first && v) atomicAdd(&st->light_pdf_tests, v);
+        v = wave_sum(ndraws); if (first && v) atomicAdd(&st->rng_draws, v);
+#pragma unroll
+        for (int i = 0; i < RT_KIND_COUNT; i++) { v = wave_sum(prims[i]); if (first && v) atomicAdd(&st->prim_tests[i], v); }
         paths = rays = nodes = lpdf = ndraws = 0;
 #pragma unroll
         for (int i = 0; i < RT_KIND_COUNT; i++) prims[i] = 0;

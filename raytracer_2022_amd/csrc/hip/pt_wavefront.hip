@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         for (uint32_t i = tid; i < (uint32_t)S / 4; i += kBlock) dst[i] = src[i];
     }
     if (tid == 0 && n_traced) atomicAdd(pool.n_active, n_traced);
-    if (STATS) cnt.flush(a.stats);
+    if (STATS) cnt.flush_wave(a.stats);
 }
 
 // =====================================================================================
@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         }
     }
     if (STATS) {
-        cnt.flush(stats);
+        cnt.flush_wave(stats);
         if (lane == 0 && stats)
             for (int o = 0; o < 9; o++) {
                 if (census_rounds[o]) atomicAdd(&stats->op_rounds[o], (unsigned long long)census_rounds[o]);
