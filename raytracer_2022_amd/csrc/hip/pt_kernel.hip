@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(kBlock) pt_megakernel(const SceneDev s, const 
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win.t = 0.0; L.win.leaf = 0; L.win.face = 0; L.win.chain = L.ctx;
     const double t_min = a.t_min;
-    const int node_quorum = (int)a.node_quorum;
+    const int node_quorum = (int)(a.node_quorum & 0xFFu);          // (the upper bits are wavefront-engine tuning)
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to.

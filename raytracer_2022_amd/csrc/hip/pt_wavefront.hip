@@ -417,6 +417,7 @@ struct TLane {
     int sp;
     uint32_t top, op;
     bool has_ray;
+    bool plain;            // the fast node step applies to this ray (see there)
 };
 
 template <int STACK>
@@ -426,10 +427,13 @@ struct TStack {
     RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * kBlock]; } return REF_EMPTY; }
 };
 
-RT_DEV void t_set_cur(TLane &L, const XRay &c) {
+RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
+RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
     L.inv = Vec3(1.0 / c.d.x, 1.0 / c.d.y, 1.0 / c.d.z);
     L.a_len = c.d.length_sqr();
+    L.plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
+              L.inv.z != 0.0 && t_finite(c.o.x) && t_finite(c.o.y) && t_finite(c.o.z);
 }
 RT_DEV double t_hi(const TLane &L) { return L.med_ref ? L.sub_closest : L.closest; }
 RT_DEV void t_accept(TLane &L, double t, uint32_t face) {
@@ -528,54 +532,64 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     if (n_list == 0) return;
 
     TLane L;
-    L.has_ray = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.steps = 0;
+    L.has_ray = false; L.plain = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
     L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
     const int sphere_reps = (int)((node_quorum_u >> 8) & 0xFu) + 1;
+    const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to.
         for (;;) {
-            bool isn = L.op == OP_NODE;
+            bool isn = L.op == OP_NODE && L.plain;
             int nn = __popcll(__ballot(isn));
             if (nn < node_quorum) break;
             if (STATS && lane == 0) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; }
             if (isn) {
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
                 // at once, the right one waits on the stack and is tested against the then-closest hit.
+                //
+                // For a `plain` ray (t_set_cur: every 1/d finite and non-zero, origin finite) against
+                // finite boxes with min <= max, no t0 / t1 is NaN and the products are ordered by the
+                // sign of 1/d, so the swap of aabb.rs:22-24 is min / max of the pair; the interval only
+                // shrinks from axis to axis, so the per-axis `t_max <= t_min` exits equal one test at
+                // the end. Any other ray takes the literal restatement in the voted arm below.
+                //
+                // Straight-line on purpose: the node's 64 bytes and the stack entry below the top are
+                // requested together, before the arithmetic — no load waits for the outcome of the test.
                 cnt.node();
                 L.steps++;
                 const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + RT_REF_INDEX(L.top));
                 uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                const int below_sp = L.sp > 0 ? L.sp - 1 : 0;
+                const uint32_t below = st.col[below_sp * kBlock];
                 double bmin[3] = {rtm::u2d(((uint64_t)q0.y << 32) | q0.x), rtm::u2d(((uint64_t)q0.w << 32) | q0.z), rtm::u2d(((uint64_t)q1.y << 32) | q1.x)};
                 double bmax[3] = {rtm::u2d(((uint64_t)q1.w << 32) | q1.z), rtm::u2d(((uint64_t)q2.y << 32) | q2.x), rtm::u2d(((uint64_t)q2.w << 32) | q2.z)};
-                uint32_t left = q3.x, right = q3.y;
+                const uint32_t left = q3.x, right = q3.y;
                 double tmn = L.t_lo, tmx = t_hi(L);
-                bool miss = false;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    double inv_d = L.inv[i];
-                    double t0 = (bmin[i] - L.cur.o[i]) * inv_d;
-                    double t1 = (bmax[i] - L.cur.o[i]) * inv_d;
-                    if (inv_d < 0.0) { double tmp = t0; t0 = t1; t1 = tmp; }
-                    tmn = t0 > tmn ? t0 : tmn;
-                    tmx = t1 < tmx ? t1 : tmx;
-                    miss = miss || (tmx <= tmn);
+                    double t0 = (bmin[i] - L.cur.o[i]) * L.inv[i];
+                    double t1 = (bmax[i] - L.cur.o[i]) * L.inv[i];
+                    tmn = __builtin_fmax(tmn, __builtin_fmin(t0, t1));
+                    tmx = __builtin_fmin(tmx, __builtin_fmax(t0, t1));
                 }
+                const bool hit = !(tmx <= tmn);
                 // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
                 // primitive a second time against t_max = its own t finds the same hit again, so
                 // only the count of tests is kept; anything that can draw from the RNG or carry
                 // movers (media, movers, nodes, lists) is really visited twice.
                 const uint32_t lk = RT_REF_KIND(left);
                 const bool twin = left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING;
-                uint32_t next = left;                             // (select, not branch: keeps the child refs' load up front)
-                if (miss) next = st.pop(L);
-                else if (twin) cnt.prim(lk);
-                else st.push(L, right);
+                const bool push = hit && !twin && L.sp < STACK;
+                if (push) st.col[L.sp * kBlock] = right;
+                if (STATS && hit && twin) cnt.prim(lk);
+                const uint32_t next = hit ? left : (L.sp > 0 ? below : REF_EMPTY);
+                L.sp = hit ? L.sp + (push ? 1 : 0) : below_sp;
                 L.top = next;
                 L.op = classify(next);                            // (media met here start in their own arm)
             }
@@ -686,7 +700,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             if (L.top == REF_POPCTX) {
                 L.ctx.n--;
                 Ray wr = pv.load_ray(L.slot);
-                t_set_cur(L, ray_at_level(s, L.ctx, L.ctx.n, XRay{wr.orig, wr.dir}));
+                t_set_cur(L, ray_at_level(s, L.ctx, L.ctx.n, XRay{wr.orig, wr.dir}), boxes_plain);
                 T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -697,7 +711,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                     T_NEXT();
                 } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
                     L.ctx.push(L.top);
-                    t_set_cur(L, xform_ray(s, L.top, L.cur));
+                    t_set_cur(L, xform_ray(s, L.top, L.cur), boxes_plain);
                     st.push(L, REF_POPCTX);
                     L.top = s.xforms[idx].child;
                     T_SETTLE();
@@ -737,7 +751,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 Ray wr = pv.load_ray(L.slot, rs);
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
-                t_set_cur(L, XRay{wr.orig, wr.dir});
+                t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
                 L.closest = rtm::F64_MAX;
                 L.steps = 0;
                 L.t_lo = t_min; L.med_ref = 0;

@@ -3,6 +3,7 @@
 // HIP device and reports RT_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -68,6 +69,15 @@ struct Validator {
         RT_REQUIRE(idx < pool_size(kind), RT_ERR_INVALID, std::string(where) + ": ref index out of range");
         if (kind >= RT_KIND_TRANSLATE && kind <= RT_KIND_ZOOM)
             RT_REQUIRE(d.xforms[idx].kind == kind, RT_ERR_INVALID, std::string(where) + ": mover ref kind does not match its record");
+    }
+    // Node boxes as the reference builds them (min / max of real coordinates): finite and ordered.
+    bool boxes_plain() const {
+        for (uint32_t i = 0; i < d.n_nodes; i++)
+            for (int a = 0; a < 3; a++) {
+                double lo = d.nodes[i].bmin[a], hi = d.nodes[i].bmax[a];
+                if (!(std::isfinite(lo) && std::isfinite(hi) && lo <= hi)) return false;
+            }
+        return true;
     }
     void check_mat(uint32_t mat, const char *where) const {
         RT_REQUIRE(mat < d.n_materials, RT_ERR_INVALID, std::string(where) + ": material index out of range");
@@ -237,6 +247,7 @@ struct rt_scene {
     uint32_t stack_need = 1;
     unsigned features = 7;
     bool general_boundaries = false;
+    bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
     uint32_t node_quorum = 18u | (1u << 8) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; long-first classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
@@ -344,7 +355,8 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     } else {
         a.partial = d_out;
     }
-    a.node_quorum = sc->node_quorum;
+    // bit 31: boxes are plain (see wf_trace's fast path); bit 30 of the tuning word forces the literal step
+    a.node_quorum = (sc->node_quorum & 0x7FFFFFFFu) | ((sc->boxes_plain && !(sc->node_quorum & (1u << 30))) ? (1u << 31) : 0u);
     a.vote_weights = sc->vote_weights;
     a.work_counter = w.work_counter;
     a.stats = counters ? w.stats : nullptr;
@@ -466,6 +478,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.n_lights = desc->n_lights;
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
+            sc->boxes_plain = v.boxes_plain();
             sc->features = ((desc->n_triangles || desc->n_rings) ? kFeatMisc : 0u) |
                            ((desc->n_xforms || desc->n_lists) ? kFeatMovers : 0u) |
                            ((desc->n_boxes || desc->n_media) ? kFeatVolumes : 0u);
@@ -599,7 +612,7 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
-        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + long-first class shift << 20)");
+        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + long-first class shift << 20, + 1 << 30: literal node step only)");
         for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
         scene->vote_weights = vote_weights;

@@ -188,6 +188,75 @@ def test_deep_stacks_select_the_larger_kernels(rt, O):
     assert e.value.code == F.RT_ERR_UNSUPPORTED
 
 
+def test_node_step_variants(rt, O):
+    """The traversal's short node step (min / max slabs, one exit test) is only taken where it provably
+    equals AABB::hit (aabb.rs:15-32); everything else runs the literal restatement. Both against the oracle."""
+    # 1. literal step forced on a scene that normally takes the short one
+    c, g, s, cam, p = golden_case("final_scene", rt)
+    dev = rt.DeviceScene(s.desc)
+    dev.set_tuning(18 | (1 << 8) | (2 << 20) | (1 << 30))
+    out, st = dev.render(cam, p, g["rows"], want_stats=True)
+    assert st.as_dict() == c["counters"] and np.array_equal(bits(out), bits(g["rgb_sum"]))
+    assert np.array_equal(bits(dev.render(cam, p, g["rows"])), bits(g["rgb_sum"]))
+
+    def grid_scene(inf_root=False, inverted=False):
+        b = rt.DescBuilder()
+        lam = b.lambertian((0.7, 0.6, 0.5))
+        met = b.metal((0.8, 0.8, 0.9), 0.0)
+        # unit spheres on integer centres: box faces fall on the integer planes the camera rays start in
+        leaves = []
+        for i, (x, y, z) in enumerate([(1, 0, -6), (-1, 0, -6), (0, 3, -7), (0, -2, -5), (3, 1, -8), (-3, -1, -4), (0, 1, -10)]):
+            sp = b.sphere((x, y, z), 1.0, met if i % 2 else lam)
+            leaves.append((sp, (x - 1, y - 1, z - 1), (x + 1, y + 1, z + 1)))
+        floor = b.rect(F.RT_RECT_XZ, -20, 20, -20, 20, -3.0, lam)
+        leaves.append((floor, (-20, -3.0001, -20), (20, -2.9999, 20)))
+        lamp = b.rect(F.RT_RECT_XZ, -2, 2, -8, -4, 6.0, b.diffuse_light((9, 9, 9)), flip=True)
+        leaves.append((lamp, (-2, 5.9999, -8), (2, 6.0001, -4)))
+        b.light(F.make_ref(F.RT_KIND_RECT, 1))         # (the light list holds the plain rect, as scene.rs does)
+        def build(items):
+            if len(items) == 1:
+                r, lo, hi = items[0]
+                return b.node(lo, hi, r, r), lo, hi
+            h = len(items) // 2
+            l, llo, lhi = build(items[:h])
+            r, rlo, rhi = build(items[h:])
+            lo = tuple(min(a, c_) for a, c_ in zip(llo, rlo)); hi = tuple(max(a, c_) for a, c_ in zip(lhi, rhi))
+            return b.node(lo, hi, l, r), lo, hi
+        root, lo, hi = build(leaves)
+        if inf_root:
+            root = b.node((-np.inf,) * 3, (np.inf,) * 3, root, root)
+        if inverted:                                   # a box with min > max on x: never hit, by either formulation of the test
+            dead = b.sphere((0, 0, -3), 0.5, lam)
+            root = b.node(lo, hi, root, b.node((1, -1, -4), (-1, 1, -2), dead, dead))
+        b.set_root(root)
+        return b.desc()
+
+    W, H, spp = 40, 30, 6
+    rows = np.arange(H, dtype=np.uint32)
+    p = rt.make_params(W, H, spp, 12, (0.3, 0.4, 0.6), seed=5)
+    ordinary = rt.camera_new((0.3, 0.2, 4), (0, 0, -6), (0, 1, 0), 50.0, W / H, 0.0, 10.0, 0.0, 1.0)
+    # 2. every camera ray is (0, 0, -1) from an integer point: 1/d = +-inf on two axes and 0 * inf = NaN at the
+    #    box faces through the origin's coordinates — AABB::hit's comparisons with NaN, kept literally
+    axis = F.rt_camera.from_buffer_copy(ordinary)
+    for k, v in (("origin", (0.0, 1.0, 4.0)), ("lower_left_corner", (0.0, 1.0, 3.0)), ("horizontal", (0.0, 0.0, 0.0)),
+                 ("vertical", (0.0, 0.0, 0.0))):
+        setattr(axis, k, (C.c_double * 3)(*v))
+    axis.lens_radius = 0.0
+    for label, d, cam in (("plain boxes", grid_scene(), ordinary), ("axis-parallel rays", grid_scene(), axis),
+                          ("infinite root box", grid_scene(inf_root=True), ordinary),
+                          ("infinite root box, axis-parallel rays", grid_scene(inf_root=True), axis),
+                          ("inverted box", grid_scene(inverted=True), ordinary)):
+        ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=4, want_stats=True)
+        for engine in ("wavefront", "mega"):
+            dev = rt.DeviceScene(d)
+            dev.set_engine(engine)
+            out, st = dev.render(cam, p, rows, want_stats=True)
+            assert st.as_dict() == st_ref.as_dict(), (label, engine)
+            assert np.array_equal(bits(out), bits(ref)), (label, engine)
+            assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), (label, engine)
+    assert st_ref.node_visits > 0
+
+
 def test_medium_with_a_composite_boundary(rt, O):
     """ConstantMedium<H> for any H (constantmedium.rs:14-22): a boundary that is a BVH of a box and a sphere.
     The two boundary queries run through the ordinary traversal arms with their own t window."""
