@@ -17,8 +17,11 @@ int rt_debug_math_device(int op, const double *a, const double *b, double *out, 
 int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n);
 /* Scheduler knobs of the traversal kernels. node_quorum: bits 0-7 = lanes that must want a BVH-node
  * step before the wave takes the node fast path without a vote (1..64); bits 8-11 = extra sphere tests
- * a lane may take in one turn; bits 20-23 = s: each workgroup's ray list is ordered longest-first by
- * (node steps of the path's previous ray) >> s, 0 = slot order. vote_weights: 4 bits per
+ * a lane may take in one turn; bits 12-15 = f: below the quorum the fast path still goes on while the
+ * node lanes outnumber f x all other pending lanes; bits 16-19 = segments of 4096 path slots a
+ * traversal workgroup works through per pass (1..8); bits 20-23 = s: each workgroup's ray list is
+ * ordered longest-first by (node steps of the path's previous ray) >> s, 0 = slot order; bit 30 = take
+ * the literal AABB step only (test hook). vote_weights: 4 bits per
  * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label
  * with the largest lanes * weight. They affect speed only, never results. */
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights);

@@ -81,7 +81,13 @@ struct WfPool {
     double *pixel_sum;      // [P][4]  running sum of the item (4th double unused)
     double *tape;           // [P][tape_cap][4] bounce records {w.x, w.y, w.z, p}
     uint32_t tape_cap;      // records per slot (>= max_depth)
-    uint16_t *prev_steps;   // [P] node steps of the slot's previous ray (0 for a camera ray): long-first ordering
+    // Ray list of every segment (= the 4096 slots one shade workgroup owns), written by the shade pass:
+    // local indices of the slots that carry a ray, longest expected traversal first. A trace workgroup
+    // works through the lists of `segs` consecutive segments.
+    uint16_t *list;         // [P]
+    uint32_t *list_n;       // [n_blocks]
+    uint32_t segs;          // segments per trace workgroup (n_blocks is a multiple of it)
+    uint16_t *cam_steps;    // [P] node steps of the slot's latest camera ray: predicts the next sample's
     uint32_t *n_active;     // paths handed to the next trace pass (polled by the host)
 };
 

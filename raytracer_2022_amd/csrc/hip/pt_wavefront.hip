@@ -68,19 +68,25 @@ struct PoolView {
     }
     RT_DEV void store_rng(uint32_t slot, uint64_t rng_state) const { p.ray[(uint64_t)slot * 8 + 7] = rtm::u2d(rng_state); }
     // Winner of the traversal: one 32-byte record per slot.
+    // meta = box face | movers << 4 | node steps of the traversal << 16 (the shade pass orders the next
+    // trace pass by them); a miss stores the first half only, for the steps.
     RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch) const {
         uint4 *q = reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8);
         uint64_t tb = rtm::d2u(t);
         q[0] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta);
         if (ch.n > 0) q[1] = make_uint4(ch.c0, ch.c1, ch.c2, ch.c3);
     }
-    RT_DEV void load_hit(uint32_t slot, Winner &w) const {
+    RT_DEV void store_miss(uint32_t slot, uint32_t meta) const {
+        reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8)[0] = make_uint4(0u, 0u, REF_EMPTY, meta);
+    }
+    RT_DEV void load_hit(uint32_t slot, Winner &w, uint32_t &steps) const {
         const uint4 *q = reinterpret_cast<const uint4 *>(p.hit + (uint64_t)slot * 8);
         uint4 a = q[0];
         w.t = rtm::u2d(((uint64_t)a.y << 32) | a.x);
         w.leaf = a.z;
         w.face = a.w & 0xFu;
-        w.chain.n = a.w >> 4;
+        w.chain.n = (a.w >> 4) & 0xFu;
+        steps = a.w >> 16;
         w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
         if (w.chain.n > 0) { uint4 b = q[1]; w.chain.c0 = b.x; w.chain.c1 = b.y; w.chain.c2 = b.z; w.chain.c3 = b.w; }
     }
@@ -156,8 +162,9 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __shared__ uint32_t hist[SK_COUNT];
     __shared__ uint32_t cursor[SK_COUNT];
     __shared__ uint32_t sorted[S];
-    __shared__ uint32_t n_sorted, n_traced;
-    __shared__ uint8_t new_kind[S];      // the slots' next state, written back in one coalesced sweep
+    __shared__ uint32_t n_sorted;
+    __shared__ uint8_t new_kind[S];      // the slots' next state (| list class << 4), written back in one coalesced sweep
+    __shared__ uint32_t bins[16];
     const RenderArgs &a = *ap;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
@@ -166,7 +173,6 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     Counters<STATS> cnt;
 
     if (tid < SK_COUNT) hist[tid] = 0;
-    if (tid == 0) n_traced = 0;
     __syncthreads();
     // Counting sort of the block's slots by kind (idle slots and nothing else are dropped).
     uint32_t my_kind[S / kBlock];
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __syncthreads();
     const uint32_t total = n_sorted;
     const Vec3 background = ld3(a.background);
-    uint32_t my_traced = 0;
+    const uint32_t step_shift = (a.node_quorum >> 20) & 0xFu;         // list class = expected steps >> shift (0 = slot order)
 
     for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
         const uint32_t j = j0 + tid;
@@ -210,14 +216,22 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         SlotState stt{};
         Winner w;
         w.t = 0.0; w.leaf = 0; w.face = 0; w.chain.n = 0; w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
+        uint32_t steps = 0;          // node steps of the ray that has just been traced
+        uint32_t cam_steps = 0;      // ... of the slot's latest camera ray
         if (on) {
             uint64_t rs;
             r = pv.load_ray(slot, rs);
             rng = Rng(rs);
             stt = load_state(pool, slot);
-            pv.load_hit(slot, w);
+            pv.load_hit(slot, w, steps);
+            cam_steps = pool.cam_steps[slot];
         }
         uint32_t depth = stt.depth;
+        // Expected length of the slot's next traversal, for the order of the trace pass's list: a bounce
+        // ray is taken to resemble the ray before it; the next sample's camera ray resembles this sample's
+        // (same pixel). Ordering only: results never depend on it.
+        uint32_t expect = steps;
+        if (on && kind >= SK_MISS && depth == a.max_depth) { cam_steps = steps; pool.cam_steps[slot] = (uint16_t)steps; }
 
         if (on && kind >= SK_MISS) {
             if (kind == SK_MISS) {
@@ -352,7 +366,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 double u = ((double)px + rand_u) / (double)(a.width - 1);
                 double v = ((double)py + rand_v) / (double)(a.height - 1);
                 r = get_ray(a.cam, u, v, rng);
-                pool.prev_steps[slot] = 0;
+                expect = cam_steps;
                 depth = a.max_depth;
                 smp++;
                 cnt.path();
@@ -372,20 +386,40 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 pv.store_ray(slot, r, rng.s);
                 stt.depth = depth;
                 store_state(pool, slot, stt);
-                new_kind[slot - base] = (uint8_t)SK_TRACE;
-                my_traced++;
+                uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
+                new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
             }
         }
     }
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
-    if (my_traced) atomicAdd(&n_traced, my_traced);
+    if (tid < 16) bins[tid] = 0;
     __syncthreads();
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(new_kind);
         uint32_t *dst = reinterpret_cast<uint32_t *>(pool.kind + base);
-        for (uint32_t i = tid; i < (uint32_t)S / 4; i += kBlock) dst[i] = src[i];
+        for (uint32_t i = tid; i < (uint32_t)S / 4; i += kBlock) dst[i] = src[i] & 0x0F0F0F0Fu;
     }
-    if (tid == 0 && n_traced) atomicAdd(pool.n_active, n_traced);
+    // The segment's ray list, longest expected traversal first (counting sort, 16 classes): the stragglers of
+    // the trace pass then start early instead of keeping a few lanes busy after the list has run dry.
+    uint32_t my_key[S / kBlock];
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++) {
+        uint32_t e = new_kind[i * kBlock + tid];
+        uint32_t key = 16;                                             // carries no ray
+        if ((e & 0xFu) == SK_TRACE) { key = 15u - (e >> 4); atomicAdd(&bins[key], 1u); }
+        my_key[i] = key;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 16; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
+        pool.list_n[blockIdx.x] = acc;
+        if (acc) atomicAdd(pool.n_active, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S / kBlock; i++)
+        if (my_key[i] < 16) pool.list[base + atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
     if (STATS) cnt.flush_wave(a.stats);
 }
 
@@ -487,48 +521,23 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
     __shared__ uint32_t stack_lds[STACK * kBlock];
-    __shared__ uint16_t list[S];
-    __shared__ uint32_t list_n, list_next;
-    __shared__ uint32_t bins[16];
+    __shared__ uint32_t seg_end[8];          // running totals of the segments' list lengths
+    __shared__ uint32_t list_next;
     const PoolView pv{pool};
-    const uint32_t base = blockIdx.x * (uint32_t)S;
+    const uint32_t seg0 = blockIdx.x * pool.segs;
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
     TStack<STACK> st{stack_lds + tid};
 
-    if (tid == 0) { list_n = 0; list_next = 0; }
-    __syncthreads();
-    // Compact the slots that carry a ray into the list, longest expected traversal first (counting sort
-    // on the node steps of the path's previous ray, 16 classes): the stragglers of this pass then start
-    // early instead of keeping a few lanes busy after the list has run dry.
-    const uint32_t step_shift = (node_quorum_u >> 20) & 0xFu;        // class = steps >> shift (0 = plain slot order)
-    if (tid < 16) { bins[tid] = 0; }
-    __syncthreads();
-    uint32_t my_key[S / kBlock];
-#pragma unroll
-    for (int i = 0; i < S / kBlock; i++) {
-        uint32_t local = (uint32_t)(i * kBlock) + tid;
-        uint32_t key = 16;                                             // not pending
-        if (pool.kind[base + local] == SK_TRACE) {
-            uint32_t cls = step_shift ? ((uint32_t)pool.prev_steps[base + local] >> step_shift) : 0u;
-            key = 15u - (cls > 15u ? 15u : cls);
-            atomicAdd(&bins[key], 1u);
-        }
-        my_key[i] = key;
-    }
-    __syncthreads();
+    // The ray lists of this workgroup's segments (written by the shade pass) are worked through back to back.
     if (tid == 0) {
         uint32_t acc = 0;
-        for (int k = 0; k < 16; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
-        list_n = acc;
+        for (uint32_t i = 0; i < 8; i++) { if (i < pool.segs) acc += pool.list_n[seg0 + i]; seg_end[i] = acc; }
+        list_next = 0;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < S / kBlock; i++)
-        if (my_key[i] < 16) list[atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
-    __syncthreads();
-    const uint32_t n_list = list_n;
+    const uint32_t n_list = seg_end[7];
     if (n_list == 0) return;
 
     TLane L;
@@ -539,6 +548,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
     const int sphere_reps = (int)((node_quorum_u >> 8) & 0xFu) + 1;
+    const int tail_factor = (int)((node_quorum_u >> 12) & 0xFu);      // (0 would mean: stay whenever a node lane exists)
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -547,7 +557,14 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         for (;;) {
             bool isn = L.op == OP_NODE && L.plain;
             int nn = __popcll(__ballot(isn));
-            if (nn < node_quorum) break;
+            if (nn < node_quorum) {
+                // Below the quorum the vote decides — except where its outcome is known: node steps weigh
+                // 1 and everything else 2 by default, so with nn > 2 x (all other pending lanes) the vote
+                // would pick the node step anyway (the usual case at the tail of a pass, when the list has
+                // run dry and a few long rays are left). Staying here saves the vote.
+                int others = __popcll(__ballot(!isn && L.op != OP_IDLE));
+                if (nn == 0 || nn <= tail_factor * others) break;
+            }
             if (STATS && lane == 0) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; }
             if (isn) {
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
@@ -726,8 +743,10 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 uint32_t slot = L.slot;
                 bool found = L.win_leaf != REF_EMPTY;
                 uint32_t kind = SK_MISS;
+                const uint32_t steps16 = (L.steps > 0xFFFFu ? 0xFFFFu : L.steps) << 16;
+                if (!found) pv.store_miss(slot, steps16);
                 if (found) {
-                    pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4), L.win_chain);
+                    pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain);
                     const rt_material &wm = s.materials[leaf_material(s, L.win_leaf)];
                     uint32_t mk = wm.kind;
                     kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_METAL ? SK_METAL
@@ -735,7 +754,6 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                     if (mk == RT_MAT_LAMBERTIAN) kind = SK_LAMB_SOLID + s.textures[wm.tex].kind;   // SOLID, CHECKER, NOISE, IMAGE
                 }
                 pool.kind[slot] = (uint8_t)kind;
-                pool.prev_steps[slot] = (uint16_t)(L.steps > 0xFFFFu ? 0xFFFFu : L.steps);
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
@@ -746,7 +764,11 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             wbase = __shfl(wbase, leader);
             uint32_t mine = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (mine < n_list) {
-                L.slot = base + list[mine];
+                uint32_t seg = 0, start = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) { uint32_t e = seg_end[i]; bool ge = mine >= e; seg += ge ? 1u : 0u; start = ge ? e : start; }
+                const uint32_t sbase = (seg0 + seg) * (uint32_t)S;
+                L.slot = sbase + pool.list[sbase + (mine - start)];
                 uint64_t rs;
                 Ray wr = pv.load_ray(L.slot, rs);
                 L.tm = wr.tm;
@@ -778,9 +800,9 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
 
 // Marks the first `used` slots of every workgroup FRESH and the rest IDLE: a small job is spread
 // over all workgroups (a few slots each) instead of filling a few workgroups to the brim.
-__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint32_t n_slots, uint32_t used) {
+__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint16_t *cam_steps, uint32_t n_slots, uint32_t used) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_slots) kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE;
+    if (i < n_slots) { kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE; cam_steps[i] = 0; }
 }
 
 // ---- host side of the engine -------------------------------------------------------------
@@ -801,7 +823,7 @@ static void launch_shade(const WfLaunch &w) {
 }
 template <int STACK, bool STATS, unsigned FEAT>
 static void launch_trace(const WfLaunch &w) {
-    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
+    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(w.blocks / w.pool.segs), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
                        w.node_quorum, w.vote_weights, w.stats);
 }
 template <int STACK>
@@ -831,7 +853,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         uint32_t used = (uint32_t)(per_block > (uint64_t)S ? (uint64_t)S : (per_block + 63) / 64 * 64);
         if (used < 64) used = 64;
         uint32_t n = blocks * (uint32_t)S;
-        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, n, used);
+        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, pool.cam_steps, n, used);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     uint32_t iterations = 0;

@@ -248,7 +248,7 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; long-first classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (2u << 16) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; 2 segments per trace workgroup; list classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
@@ -317,7 +317,9 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.pixel_sum = pool_alloc<double>(w, 4 * P);
     q.tape = pool_alloc<double>(w, (uint64_t)depth * 4 * P);
     q.tape_cap = depth;
-    q.prev_steps = pool_alloc<uint16_t>(w, P);
+    q.list = pool_alloc<uint16_t>(w, P);
+    q.list_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
+    q.cam_steps = pool_alloc<uint16_t>(w, P);
     q.n_active = pool_alloc<uint32_t>(w, 1);
     w.pool_slots = slots;
     w.pool_depth = depth;
@@ -364,11 +366,20 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Wavefront engine: pool of path slots, shade / trace passes until it drains.
         hipDeviceProp_t prop;
         RT_HIP(hipGetDeviceProperties(&prop, sc->device));
-        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 5u * (uint32_t)prop.multiProcessorCount;
+        // Pool = segments of 4096 path slots (one shade workgroup each); a trace workgroup works through
+        // `segs` of them — the more rays a wave sees per pass, the smaller the share of its under-filled tail.
+        // Five trace workgroups per CU are resident at a time.
+        uint32_t segs = (sc->node_quorum >> 16) & 0xFu;
+        if (segs < 1) segs = 1;
+        if (segs > 8) segs = 8;
+        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 5u * (uint32_t)prop.multiProcessorCount * segs;
         // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
         uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+        if (blocks < segs) segs = blocks;
+        blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
+        w.pool.segs = segs;
         a.tape = nullptr;
         RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
         if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
@@ -612,7 +623,7 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
-        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + long-first class shift << 20, + 1 << 30: literal node step only)");
+        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + tail factor << 12, + segments per trace workgroup << 16, + long-first class shift << 20, + 1 << 30: literal node step only)");
         for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
         scene->vote_weights = vote_weights;

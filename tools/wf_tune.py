@@ -17,14 +17,16 @@ s = rt.HostScene(name, seed=2022)
 cam, bg = s.default_view(W / H)
 rows = np.arange(H, dtype=np.uint32)
 dev = rt.DeviceScene(s.desc)
-p0 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
+p0 = rt.make_params(W, H, min(spp, 20), 50, bg, seed=2022, spp_chunk=1)
 dev.set_tuning()
 out, st = dev.render(cam, p0, rows, want_stats=True)
-rays = st.rays
+rays = st.rays * (spp / min(spp, 20))      # (estimate: the counter pass runs at most 20 spp)
 print('rays', rays, flush=True)
 for k, v in dev.census().items():
     print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
-cfgs = [('wavefront', 1280, 1, 18 + 0x100 + (2 << 20), 0x22222221)] * 2
+def Q(q=18, reps=1, tail=2, segs=2, shift=2):
+    return q | (reps << 8) | (tail << 12) | (segs << 16) | (shift << 20)
+cfgs = [('wavefront', 0, 10, Q(segs=g), 0x22222221) for g in (1, 2, 3, 4)] + [('wavefront', 0, 10, Q(segs=2, shift=sh), 0x22222221) for sh in (1, 3)]
 for eng, blocks, chunk, q, wts in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
