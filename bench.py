@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (a reduced-spp run is NOT the headline number)")
-    ap.add_argument("--spp-chunk", type=int, default=10)
+    ap.add_argument("--spp-chunk", type=int, default=1)
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)

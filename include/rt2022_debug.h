@@ -20,7 +20,9 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  * a lane may take in one turn; bits 12-15 = f: below the quorum the fast path still goes on while the
  * node lanes outnumber f x all other pending lanes; bits 16-19 = segments of 4096 path slots a
  * traversal workgroup works through per pass (1..8); bits 20-23 = s: each workgroup's ray list is
- * ordered longest-first by (node steps of the path's previous ray) >> s, 0 = slot order; bit 30 = take
+ * ordered longest-first by (node steps of the path's previous ray) >> s, 0 = slot order; bits 24-27 = groups the
+ * pool is cut into, each alternating its passes on a stream of its own (1..8); bit 29 = run
+ * the pass-timing probe (rt_debug_pass_timing); bit 30 = take
  * the literal AABB step only (test hook). vote_weights: 4 bits per
  * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label
  * with the largest lanes * weight. They affect speed only, never results. */
@@ -33,6 +35,11 @@ int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks);
  * per operation label (node, sphere, rect, box, medium, misc, ctx, done; [8] = node fast path) the
  * number of wave-rounds and the lanes they served: lanes / (64 * rounds) = lane utilisation. */
 int rt_debug_census(const rt_scene *scene, uint64_t rounds[9], uint64_t lanes[9]);
+/* Timing probe of the traversal passes of the last render made with tuning bit 29 set (the host then
+ * synchronises after every pass): sums over passes, in 100 MHz ticks, of {pass span (first wave start
+ * to last wave end), mean wave lifetime, mean wave time after the workgroup's ray list ran dry}, then
+ * {passes, waves}. lifetime / span = how evenly the waves finish; dry / lifetime = the under-filled tail. */
+int rt_debug_pass_timing(const rt_scene *scene, double out[5]);
 /* Traversal-stack entries the scene needs and the persistent grid size used for it. */
 int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
 

@@ -88,7 +88,10 @@ struct WfPool {
     uint32_t *list_n;       // [n_blocks]
     uint32_t segs;          // segments per trace workgroup (n_blocks is a multiple of it)
     uint16_t *cam_steps;    // [P] node steps of the slot's latest camera ray: predicts the next sample's
-    uint32_t *n_active;     // paths handed to the next trace pass (polled by the host)
+    uint32_t *n_active;     // [2] rays handed to the next trace pass, by pass parity (polled by the host)
+    // Pass-timing probe (rt_debug_pass_timing; null otherwise): {first wave start, last wave end, sum of
+    // wave lifetimes, sum of wave time after the list ran dry, waves} in wall_clock64 ticks.
+    unsigned long long *dbg;
 };
 
 // Traversal-stack capacities the megakernel is instantiated for.
@@ -105,11 +108,20 @@ constexpr unsigned kFeatMisc = 1;      // triangles, rings
 constexpr unsigned kFeatMovers = 2;    // Translate / RotateY / Zoom, HittableList objects
 constexpr unsigned kFeatVolumes = 4;   // Boxes, ConstantMedium
 
+// Streams the wavefront engine runs its groups of segments on (owned by the caller).
+constexpr int kMaxGroups = 8;
+struct WfStreams {
+    int n = 0;                         // groups wanted (1 = everything on the caller's stream)
+    hipStream_t stream[kMaxGroups] = {};
+    hipEvent_t ev[kMaxGroups][2] = {};
+    uint32_t *h_active = nullptr;      // pinned, [kMaxGroups][2]
+};
 // Wavefront engine: alternates shade / trace passes over the pool until it drains.
 // Blocks the calling thread (polls `n_active`). d_args is the device-resident copy of `args`.
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
-                                   uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations);
+                                   const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations,
+                                   double *timing /* null, or [5]: see rt_debug_pass_timing */);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

@@ -23,6 +23,9 @@
 //
 // Per-lane semantics never change: every path consumes its RNG stream and visits nodes
 // in the reference's order, so results stay bit-identical to the oracle.
+#include <cstdio>
+#include <cstdlib>
+
 #include "pt_common.hpp"
 
 namespace rt2022 {
@@ -158,7 +161,7 @@ RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
 // Shade pass.
 // =====================================================================================
 template <bool STATS>
-__global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool) {
+__global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool, const uint32_t parity) {
     __shared__ uint32_t hist[SK_COUNT];
     __shared__ uint32_t cursor[SK_COUNT];
     __shared__ uint32_t sorted[S];
@@ -414,7 +417,10 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         uint32_t acc = 0;
         for (int k = 0; k < 16; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
         pool.list_n[blockIdx.x] = acc;
-        if (acc) atomicAdd(pool.n_active, acc);
+        // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
+        // turns, so each pass can clear the one the next pass will add to.
+        if (acc) atomicAdd(&pool.n_active[parity], acc);
+        if (blockIdx.x == 0) pool.n_active[parity ^ 1u] = 0;
     }
     __syncthreads();
 #pragma unroll
@@ -539,6 +545,10 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     __syncthreads();
     const uint32_t n_list = seg_end[7];
     if (n_list == 0) return;
+    const bool probe = pool.dbg != nullptr;
+    unsigned long long t_start = 0, t_dry = 0;
+    bool dry_seen = false;
+    if (probe) t_start = wall_clock64();
 
     TLane L;
     L.has_ray = false; L.plain = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.steps = 0;
@@ -763,6 +773,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             if ((int)lane == leader) wbase = atomicAdd(&list_next, (uint32_t)__popcll(m));
             wbase = __shfl(wbase, leader);
             uint32_t mine = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (probe && !dry_seen && __ballot(mine >= n_list)) { dry_seen = true; t_dry = wall_clock64(); }
             if (mine < n_list) {
                 uint32_t seg = 0, start = 0;
 #pragma unroll
@@ -788,6 +799,14 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             }
         }
     }
+    if (probe && lane == 0) {
+        unsigned long long t_end = wall_clock64();
+        atomicMin(&pool.dbg[0], t_start);
+        atomicMax(&pool.dbg[1], t_end);
+        atomicAdd(&pool.dbg[2], t_end - t_start);
+        atomicAdd(&pool.dbg[3], t_end - (dry_seen ? t_dry : t_end));
+        atomicAdd(&pool.dbg[4], 1ull);
+    }
     if (STATS) {
         cnt.flush_wave(stats);
         if (lane == 0 && stats)
@@ -808,18 +827,18 @@ __global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint16_t *cam_step
 // ---- host side of the engine -------------------------------------------------------------
 struct WfLaunch {
     SceneDev scene;
-    WfPool pool;
+    WfPool pool;                // this group's view of the pool
     const RenderArgs *d_args;
     double t_min;
     uint32_t node_quorum;
     uint32_t vote_weights;
     StatsDev *stats;
-    uint32_t blocks;
+    uint32_t blocks;            // segments of the group
     hipStream_t stream;
 };
 template <bool STATS>
-static void launch_shade(const WfLaunch &w) {
-    hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool);
+static void launch_shade(const WfLaunch &w, uint32_t parity) {
+    hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
 }
 template <int STACK, bool STATS, unsigned FEAT>
 static void launch_trace(const WfLaunch &w) {
@@ -839,13 +858,30 @@ static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
         default: launch_trace<STACK, false, 7>(w); break;
     }
 }
+static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters) {
+    if (counters) launch_shade<true>(w, parity);
+    else launch_shade<false>(w, parity);
+    if (stack_need <= (uint32_t)kStackSmall) {
+        if (counters) launch_trace<kStackSmall, true, 7>(w);
+        else launch_trace_feat<kStackSmall>(features, w);
+    } else if (stack_need <= (uint32_t)kStackMid) {
+        if (counters) launch_trace<kStackMid, true, 7>(w);
+        else launch_trace_feat<kStackMid>(features, w);
+    } else {
+        if (counters) launch_trace<kStackLarge, true, 7>(w);
+        else launch_trace_feat<kStackLarge>(features, w);
+    }
+}
 
+// The pool is cut into groups of segments, each on a stream of its own and alternating shade / trace passes
+// at its own pace: nothing couples the groups but the work counter, so while the last long rays of one
+// group's trace pass keep a few waves busy, the other groups' kernels fill the rest of the chip. (Measured
+// with one group: the mean wave lives 0.41 of a trace pass — rt_debug_pass_timing.)
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
-                                   uint32_t *h_active_pinned, hipStream_t stream, uint32_t *out_iterations) {
+                                   const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const uint32_t blocks = pool.n_blocks;
-    const WfLaunch w{scene, pool, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, blocks, stream};
     hipError_t e;
     // Slots in use start FRESH (at most one work item per slot is ever needed at a time).
     {
@@ -855,32 +891,90 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         uint32_t n = blocks * (uint32_t)S;
         hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, pool.cam_steps, n, used);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
     }
+    const uint32_t trace_blocks = blocks / pool.segs;
+    int G = timing ? 1 : gs.n;
+    if (G < 1) G = 1;
+    if ((uint32_t)G > trace_blocks) G = (int)trace_blocks;
+    WfLaunch w[kMaxGroups];
+    uint32_t iter[kMaxGroups] = {};
+    uint32_t batches[kMaxGroups] = {};          // batches enqueued
+    bool drained[kMaxGroups] = {};
+    for (int g = 0; g < G; g++) {
+        const uint32_t tb0 = (uint32_t)((uint64_t)trace_blocks * g / G), tb1 = (uint32_t)((uint64_t)trace_blocks * (g + 1) / G);
+        const uint32_t seg_begin = tb0 * pool.segs, n_segs = (tb1 - tb0) * pool.segs;
+        const uint64_t off = (uint64_t)seg_begin * S;
+        WfPool v = pool;
+        v.n_blocks = n_segs; v.n_slots = n_segs * (uint32_t)S;
+        v.kind += off; v.ray += off * 8; v.hit += off * 8; v.state += off * 8; v.pixel_sum += off * 4;
+        v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin; v.cam_steps += off;
+        v.n_active = pool.n_active + 2 * g;
+        w[g] = WfLaunch{scene, v, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, n_segs, G == 1 ? stream : gs.stream[g]};
+    }
+    if (G > 1) {                                // the groups start after what the caller's stream holds so far
+        if ((e = hipEventRecord(gs.ev[0][0], stream)) != hipSuccess) return e;
+        for (int g = 0; g < G; g++)
+            if ((e = hipStreamWaitEvent(gs.stream[g], gs.ev[0][0], 0)) != hipSuccess) return e;
+        if ((e = hipEventSynchronize(gs.ev[0][0])) != hipSuccess) return e;     // (the event is reused below)
+    }
+    const uint32_t poll_every = timing ? 1 : 4;
     uint32_t iterations = 0;
-    const int poll_every = 4;
-    for (;;) {
-        for (int k = 0; k < poll_every; k++) {
-            if ((e = hipMemsetAsync(pool.n_active, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-            if (counters) launch_shade<true>(w);
-            else launch_shade<false>(w);
-            if (stack_need <= (uint32_t)kStackSmall) {
-                if (counters) launch_trace<kStackSmall, true, 7>(w);
-                else launch_trace_feat<kStackSmall>(features, w);
-            } else if (stack_need <= (uint32_t)kStackMid) {
-                if (counters) launch_trace<kStackMid, true, 7>(w);
-                else launch_trace_feat<kStackMid>(features, w);
-            } else {
-                if (counters) launch_trace<kStackLarge, true, 7>(w);
-                else launch_trace_feat<kStackLarge>(features, w);
+    // One batch = poll_every passes + a read-back of the group's "rays handed on" counter. Two batches per group
+    // are kept in flight so that a group's stream never runs empty while the host looks at the previous answer.
+    auto enqueue_batch = [&](int g) -> hipError_t {
+        for (uint32_t k = 0; k < poll_every; k++) {
+            if (timing) {
+                if ((e = hipMemsetAsync(pool.dbg, 0xFF, sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(pool.dbg + 1, 0, 4 * sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
             }
+            launch_pass(w[g], iter[g] & 1u, stack_need, features, counters);
+            iter[g]++;
             iterations++;
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(h_active_pinned, pool.n_active, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        if (*h_active_pinned == 0) break;       // the last shade pass handed no ray on: the pool has drained
-        if (iterations > (1u << 26)) return hipErrorUnknown;
+        const uint32_t b = batches[g]++ & 1u;   // ring of two: batches of a group complete in order
+        if ((e = hipMemcpyAsync(gs.h_active + 2 * g + b, w[g].pool.n_active + ((iter[g] - 1) & 1u), sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
+        return hipEventRecord(gs.ev[g][b], w[g].stream);
+    };
+    uint32_t waited[kMaxGroups] = {};           // batches whose answer has been read
+    for (int g = 0; g < G; g++) {
+        if ((e = enqueue_batch(g)) != hipSuccess) return e;
+        if (!timing && (e = enqueue_batch(g)) != hipSuccess) return e;
     }
+    int live = G;
+    while (live > 0) {
+        for (int g = 0; g < G; g++) {
+            if (drained[g]) continue;
+            const uint32_t b = waited[g] & 1u;
+            if ((e = hipEventSynchronize(gs.ev[g][b])) != hipSuccess) return e;
+            waited[g]++;
+            if (timing) {
+                unsigned long long h[5];
+                if ((e = hipMemcpy(h, pool.dbg, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+                if (h[4]) {
+                    timing[0] += (double)(h[1] - h[0]);                // span of the pass
+                    timing[1] += (double)h[2] / (double)h[4];          // mean wave lifetime
+                    timing[2] += (double)h[3] / (double)h[4];          // mean wave time after its list ran dry
+                    timing[3] += 1.0;
+                    timing[4] += (double)h[4];
+                    if (getenv("RT2022_PASS_LOG"))
+                        fprintf(stderr, "pass %u span_us %.1f life/span %.3f dry/life %.3f waves %llu rays %u\n", iter[g], (double)(h[1] - h[0]) / 100.0,
+                                (double)h[2] / (double)h[4] / (double)(h[1] - h[0]), (double)h[3] / (double)(h[2] ? h[2] : 1), h[4], gs.h_active[2 * g + b]);
+                }
+            }
+            if (gs.h_active[2 * g + b] == 0) {  // the batch's last shade pass handed no ray on: the group has drained
+                drained[g] = true;
+                live--;
+                continue;
+            }
+            if (iter[g] > (1u << 26)) return hipErrorUnknown;
+            if ((e = enqueue_batch(g)) != hipSuccess) return e;
+        }
+    }
+    for (int g = 0; g < G; g++)                 // (a drained group may still have an idle batch queued)
+        if ((e = hipStreamSynchronize(w[g].stream)) != hipSuccess) return e;
     if (out_iterations) *out_iterations = iterations;
     return hipSuccess;
 }

@@ -229,10 +229,11 @@ struct Workspace {
     WfPool pool{};
     std::vector<void *> pool_owned;
     uint32_t pool_slots = 0, pool_depth = 0;
+    unsigned long long *pool_dbg = nullptr;
     SceneDev *d_scene = nullptr;
     RenderArgs *d_args = nullptr;
     WfPool *d_pool = nullptr;
-    uint32_t *h_active = nullptr;     // pinned
+    WfStreams gs{};                   // group streams / events / pinned words (created on first use)
     uint32_t iterations = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt_stats *pending = nullptr;      // host stats to fill at rt_render_wait
@@ -248,11 +249,12 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (2u << 16) | (2u << 20);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; 2 segments per trace workgroup; list classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (2u << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; 2 segments per trace workgroup; list classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
-    int max_pool_blocks = 0;          // 0 = 5 x CUs
+    int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
+    double pass_timing[5] = {};       // of the last render with tuning bit 29 (rt_debug_pass_timing)
     int device = 0;
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
@@ -296,7 +298,11 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
         RT_HIP(hipMalloc((void **)&w.d_scene, sizeof(SceneDev)));
         RT_HIP(hipMalloc((void **)&w.d_args, sizeof(RenderArgs)));
         RT_HIP(hipMalloc((void **)&w.d_pool, sizeof(WfPool)));
-        RT_HIP(hipHostMalloc((void **)&w.h_active, sizeof(uint32_t)));
+        RT_HIP(hipHostMalloc((void **)&w.gs.h_active, 2 * kMaxGroups * sizeof(uint32_t)));
+        for (int g = 0; g < kMaxGroups; g++) {
+            RT_HIP(hipStreamCreateWithFlags(&w.gs.stream[g], hipStreamNonBlocking));
+            for (int b = 0; b < 2; b++) RT_HIP(hipEventCreateWithFlags(&w.gs.ev[g][b], hipEventDisableTiming));
+        }
     }
     if (slots <= w.pool_slots && depth <= w.pool_depth) { w.pool.n_blocks = blocks; w.pool.n_slots = w.pool_slots; return; }
     RT_HIP(hipStreamSynchronize(stream));
@@ -320,7 +326,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.list = pool_alloc<uint16_t>(w, P);
     q.list_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
     q.cam_steps = pool_alloc<uint16_t>(w, P);
-    q.n_active = pool_alloc<uint32_t>(w, 1);
+    q.n_active = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
+    w.pool_dbg = pool_alloc<unsigned long long>(w, 5);
     w.pool_slots = slots;
     w.pool_depth = depth;
 }
@@ -380,6 +387,12 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
         w.pool.segs = segs;
+        const bool timing = (sc->node_quorum & (1u << 29)) != 0;
+        w.gs.n = (int)((sc->node_quorum >> 24) & 0xFu);     // groups of segments passing independently (streams)
+        if (w.gs.n < 1) w.gs.n = 1;
+        if (w.gs.n > kMaxGroups) w.gs.n = kMaxGroups;
+        w.pool.dbg = timing ? w.pool_dbg : nullptr;
+        if (timing) for (double &t : sc->pass_timing) t = 0.0;
         a.tape = nullptr;
         RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
         if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
@@ -387,7 +400,8 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
         RT_HIP(hipEventRecord(w.ev0, stream));
         if (a.n_items > 0) {
-            RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.h_active, stream, &w.iterations));
+            RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.gs, stream, &w.iterations,
+                                           timing ? sc->pass_timing : nullptr));
             if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
         RT_HIP(hipEventRecord(w.ev1, stream));
@@ -517,7 +531,11 @@ int rt_scene_destroy(rt_scene *scene) {
             if (w.d_scene) (void)hipFree(w.d_scene);
             if (w.d_args) (void)hipFree(w.d_args);
             if (w.d_pool) (void)hipFree(w.d_pool);
-            if (w.h_active) (void)hipHostFree(w.h_active);
+            if (w.gs.h_active) (void)hipHostFree(w.gs.h_active);
+            for (int g = 0; g < kMaxGroups; g++) {
+                if (w.gs.stream[g]) (void)hipStreamDestroy(w.gs.stream[g]);
+                for (int b = 0; b < 2; b++) if (w.gs.ev[g][b]) (void)hipEventDestroy(w.gs.ev[g][b]);
+            }
             if (w.ev0) (void)hipEventDestroy(w.ev0);
             if (w.ev1) (void)hipEventDestroy(w.ev1);
         }
@@ -623,7 +641,7 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
-        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + tail factor << 12, + segments per trace workgroup << 16, + long-first class shift << 20, + 1 << 30: literal node step only)");
+        RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + tail factor << 12, + segments per trace workgroup << 16, + long-first class shift << 20, + groups << 24, + 1 << 29: pass-timing probe, + 1 << 30: literal node step only)");
         for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
         scene->vote_weights = vote_weights;
@@ -640,6 +658,14 @@ int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks) {
                    "the megakernel engine only handles media whose boundary is one primitive under movers");
         scene->engine = engine;
         scene->max_pool_blocks = max_pool_blocks;
+        return RT_OK;
+    });
+}
+
+int rt_debug_pass_timing(const rt_scene *scene, double out[5]) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene && out, RT_ERR_INVALID, "rt_debug_pass_timing: null argument");
+        for (int i = 0; i < 5; i++) out[i] = scene->pass_timing[i];
         return RT_OK;
     });
 }

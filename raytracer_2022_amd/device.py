@@ -18,12 +18,18 @@ class DeviceScene:
         F.check(F.lib().rt_debug_scene_info(self._h, C.byref(need), C.byref(blocks)))
         return {"stack_need": need.value, "grid_blocks": blocks.value}
 
-    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (2 << 16) | (2 << 20), vote_weights=0x22222221):
+    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (2 << 16) | (2 << 20) | (1 << 24), vote_weights=0x22222221):
         F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))
 
     def set_engine(self, engine, max_pool_blocks=0):
         """engine: "wavefront" (default) or "mega"."""
         F.check(F.lib().rt_debug_set_engine(self._h, {"mega": 0, "wavefront": 1}[engine], max_pool_blocks))
+
+    def pass_timing(self):
+        """Probe of the last render made with tuning bit 29: dict of sums over the traversal passes (ms)."""
+        o = (C.c_double * 5)()
+        F.check(F.lib().rt_debug_pass_timing(self._h, o))
+        return {"span_ms": o[0] / 1e5, "wave_life_ms": o[1] / 1e5, "wave_dry_ms": o[2] / 1e5, "passes": int(o[3]), "waves": int(o[4])}
 
     def census(self):
         """Scheduler census of the last counter run: {label: (rounds, lanes, utilisation)}."""

@@ -24,9 +24,15 @@ rays = st.rays * (spp / min(spp, 20))      # (estimate: the counter pass runs at
 print('rays', rays, flush=True)
 for k, v in dev.census().items():
     print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
-def Q(q=18, reps=1, tail=2, segs=2, shift=2):
-    return q | (reps << 8) | (tail << 12) | (segs << 16) | (shift << 20)
-cfgs = [('wavefront', 0, 10, Q(segs=g), 0x22222221) for g in (1, 2, 3, 4)] + [('wavefront', 0, 10, Q(segs=2, shift=sh), 0x22222221) for sh in (1, 3)]
+def Q(q=18, reps=1, tail=2, segs=2, shift=2, groups=1):
+    return q | (reps << 8) | (tail << 12) | (segs << 16) | (shift << 20) | (groups << 24)
+dev.set_tuning(Q() | (1 << 29))
+pp = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=10)
+ms = run(dev, cam, pp, rows, W)
+t = dev.pass_timing()
+print('pass timing (probe run %.1f ms): %s' % (ms, t))
+print('  mean wave lifetime / pass span = %.3f   dry tail / lifetime = %.3f' % (t['wave_life_ms'] / t['span_ms'], t['wave_dry_ms'] / t['wave_life_ms']), flush=True)
+cfgs = [('wavefront', b, 10, Q(groups=g, segs=sg), 0x22222221) for g, b, sg in ((1, 0, 2), (1, 1280, 1), (1, 1280, 2), (1, 1280, 4), (1, 640, 2), (2, 1280, 2))]
 for eng, blocks, chunk, q, wts in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
