@@ -21,7 +21,8 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  * node lanes outnumber f x all other pending lanes; bits 16-19 = segments of 4096 path slots a
  * traversal workgroup works through per pass (1..8); bits 20-23 = s: each workgroup's ray list is
  * ordered longest-first by (node steps of the path's previous ray) >> s, 0 = slot order; bits 24-27 = groups the
- * pool is cut into, each alternating its passes on a stream of its own (1..8); bit 29 = run
+ * pool is cut into, each alternating its passes on a stream of its own (1..8); bit 28 = do not
+ * pace the workgroups' issue priority; bit 29 = run
  * the pass-timing probe (rt_debug_pass_timing); bit 30 = take
  * the literal AABB step only (test hook). vote_weights: 4 bits per
  * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label

@@ -23,8 +23,10 @@
 //
 // Per-lane semantics never change: every path consumes its RNG stream and visits nodes
 // in the reference's order, so results stay bit-identical to the oracle.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "pt_common.hpp"
 
@@ -51,6 +53,7 @@ enum SlotKind : uint32_t {
 };
 
 constexpr int S = kSlotsPerBlock;
+constexpr uint32_t kPaceOne = 32768;       // a workgroup's whole list, in the units of WfPool::pace
 
 struct PoolView {
     const WfPool &p;
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
         // turns, so each pass can clear the one the next pass will add to.
         if (acc) atomicAdd(&pool.n_active[parity], acc);
-        if (blockIdx.x == 0) pool.n_active[parity ^ 1u] = 0;
+        if (blockIdx.x == 0) { pool.n_active[parity ^ 1u] = 0; *pool.pace = 0; }
     }
     __syncthreads();
 #pragma unroll
@@ -529,6 +532,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     __shared__ uint32_t stack_lds[STACK * kBlock];
     __shared__ uint32_t seg_end[8];          // running totals of the segments' list lengths
     __shared__ uint32_t list_next;
+    __shared__ uint32_t block_prio;
     const PoolView pv{pool};
     const uint32_t seg0 = blockIdx.x * pool.segs;
     const uint32_t tid = threadIdx.x;
@@ -541,10 +545,14 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         uint32_t acc = 0;
         for (uint32_t i = 0; i < 8; i++) { if (i < pool.segs) acc += pool.list_n[seg0 + i]; seg_end[i] = acc; }
         list_next = 0;
+        block_prio = 1;
     }
     __syncthreads();
     const uint32_t n_list = seg_end[7];
-    if (n_list == 0) return;
+    if (n_list == 0) {
+        if (tid == 0) atomicAdd(pool.pace, kPaceOne);
+        return;
+    }
     const bool probe = pool.dbg != nullptr;
     unsigned long long t_start = 0, t_dry = 0;
     bool dry_seen = false;
@@ -559,10 +567,33 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
     const int sphere_reps = (int)((node_quorum_u >> 8) & 0xFu) + 1;
     const int tail_factor = (int)((node_quorum_u >> 12) & 0xFu);      // (0 would mean: stay whenever a node lane exists)
+    const bool keep_pace = ((node_quorum_u >> 28) & 1u) == 0;          // (bit 28 of the tuning word switches the pacing off)
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // Issue priority. The SIMD's arbiter serves its oldest wave first, and the five workgroups of a CU start a
+    // pass together: measured, the first-dispatched fifth of the grid finished at 3.8 ms and the last at 5.3 ms,
+    // the SIMDs running ever emptier in between. So the workgroups keep pace with each other: every 64 rounds
+    // each adds its progress through its list to a global sum, compares itself with the mean and sets its waves'
+    // s_setprio — behind the field: high, ahead: low. They then arrive together and the chip stays full.
+    uint32_t pace_tick = 0, pace_reported = 0;
 
     for (;;) {
+        if (keep_pace && (pace_tick++ & 63u) == 0) {
+            if (tid == 0) {
+                const uint32_t taken = list_next < n_list ? list_next : n_list;
+                const uint32_t f = (uint32_t)(((uint64_t)taken * kPaceOne) / n_list);
+                const uint32_t sum = atomicAdd(pool.pace, f - pace_reported) + (f - pace_reported);
+                pace_reported = f;
+                const int d = (int)f - (int)(sum / gridDim.x);
+                block_prio = d < -(int)(kPaceOne / 128) ? 3u : d < 0 ? 2u : d < (int)(kPaceOne / 128) ? 1u : 0u;
+            }
+            switch (block_prio) {                                      // (a stale read is as good: the next one is 64 rounds away)
+                case 3: __builtin_amdgcn_s_setprio(3); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+        }
         // Fast path: keep stepping nodes while enough lanes want to.
         for (;;) {
             bool isn = L.op == OP_NODE && L.plain;
@@ -799,6 +830,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             }
         }
     }
+    if (tid == 0) atomicAdd(pool.pace, kPaceOne - pace_reported);       // (wave 0 leaving: the others are at the list's end too)
     if (probe && lane == 0) {
         unsigned long long t_end = wall_clock64();
         atomicMin(&pool.dbg[0], t_start);
@@ -806,6 +838,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         atomicAdd(&pool.dbg[2], t_end - t_start);
         atomicAdd(&pool.dbg[3], t_end - (dry_seen ? t_dry : t_end));
         atomicAdd(&pool.dbg[4], 1ull);
+        if (tid == 0) { pool.dbg[8 + 2 * blockIdx.x] = t_start; pool.dbg[9 + 2 * blockIdx.x] = t_end; }
     }
     if (STATS) {
         cnt.flush_wave(stats);
@@ -910,6 +943,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         v.kind += off; v.ray += off * 8; v.hit += off * 8; v.state += off * 8; v.pixel_sum += off * 4;
         v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin; v.cam_steps += off;
         v.n_active = pool.n_active + 2 * g;
+        v.pace = pool.pace + g;
         w[g] = WfLaunch{scene, v, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, n_segs, G == 1 ? stream : gs.stream[g]};
     }
     if (G > 1) {                                // the groups start after what the caller's stream holds so far
@@ -959,6 +993,24 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                     timing[2] += (double)h[3] / (double)h[4];          // mean wave time after its list ran dry
                     timing[3] += 1.0;
                     timing[4] += (double)h[4];
+                    if (getenv("RT2022_PASS_LOG") && (iter[g] == 50 || iter[g] == 51 || iter[g] == 80)) {      // wave 0 of every workgroup
+                        const uint32_t nb = w[g].blocks / w[g].pool.segs;
+                        std::vector<unsigned long long> bt(2 * nb);
+                        if (hipMemcpy(bt.data(), pool.dbg + 8, bt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                            std::vector<double> st_, en_;
+                            for (uint32_t b = 0; b < nb; b++) {
+                                st_.push_back((double)(bt[2 * b] - h[0]) / 100.0); en_.push_back((double)(bt[2 * b + 1] - h[0]) / 100.0);
+                            }
+                            if (const char *dump = getenv("RT2022_BLOCK_DUMP")) {
+                                char name[512];
+                                snprintf(name, sizeof name, "%s.%u", dump, iter[g]);
+                                if (FILE *f = fopen(name, "w")) { for (uint32_t b = 0; b < nb; b++) fprintf(f, "%u %.1f %.1f\n", b, st_[b], en_[b]); fclose(f); }
+                            }
+                            std::sort(st_.begin(), st_.end()); std::sort(en_.begin(), en_.end());
+                            fprintf(stderr, "pass %u workgroups %u: start us p0 %.1f p50 %.1f p100 %.1f | end us p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f\n", iter[g], nb,
+                                    st_[0], st_[nb / 2], st_[nb - 1], en_[0], en_[nb / 10], en_[nb / 2], en_[nb * 9 / 10], en_[nb - 1]);
+                        }
+                    }
                     if (getenv("RT2022_PASS_LOG"))
                         fprintf(stderr, "pass %u span_us %.1f life/span %.3f dry/life %.3f waves %llu rays %u\n", iter[g], (double)(h[1] - h[0]) / 100.0,
                                 (double)h[2] / (double)h[4] / (double)(h[1] - h[0]), (double)h[3] / (double)(h[2] ? h[2] : 1), h[4], gs.h_active[2 * g + b]);

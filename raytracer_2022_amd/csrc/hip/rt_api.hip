@@ -327,7 +327,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.list_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
     q.cam_steps = pool_alloc<uint16_t>(w, P);
     q.n_active = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
-    w.pool_dbg = pool_alloc<unsigned long long>(w, 5);
+    q.pace = pool_alloc<uint32_t>(w, kMaxGroups);
+    w.pool_dbg = pool_alloc<unsigned long long>(w, 8 + 2 * 65536);
     w.pool_slots = slots;
     w.pool_depth = depth;
 }
