@@ -147,7 +147,7 @@ ABI_STRUCTS = [rt_bvh_node, rt_sphere, rt_moving_sphere, rt_rect, rt_box, rt_tri
                rt_list, rt_material, rt_texture, rt_image, rt_perlin, rt_scene_desc, rt_camera, rt_params, rt_stats]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt2022.so")
+LIB_PATH = os.environ.get("RT2022_LIB") or os.path.join(_HERE, "librt2022.so")   # (RT2022_LIB: A/B builds of the same library, tools/ab.sh)
 
 # Every symbol the three headers declare (tests/test_abi.py checks the export table).
 ABI_SYMBOLS = [

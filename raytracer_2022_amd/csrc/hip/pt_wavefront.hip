@@ -492,6 +492,9 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
     if (FEAT & kFeatVolumes) {
         for (int guard = 0; guard < 6; guard++) {
             if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM) {               // a medium leaf: boundary.hit(r, -inf, inf)
+                // (a boundary that is one plain sphere — the fog and the subsurface ball of the final scene —
+                // is not traversed at all: the medium arm does both queries and the finish in one turn)
+                if (RT_REF_KIND(s.media[RT_REF_INDEX(L.top)].boundary) == RT_KIND_SPHERE) break;
                 cnt.prim(RT_KIND_MEDIUM);
                 L.med_ref = L.top;
                 L.t_lo = -rtm::INF;
@@ -523,7 +526,7 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
 
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
-template <int STACK, bool STATS, unsigned FEAT>
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
 __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 22 || (FEAT & kFeatMisc)) ? 4 : 5) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t vote_weights, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         if (tid == 0) atomicAdd(pool.pace, kPaceOne);
         return;
     }
-    const bool probe = pool.dbg != nullptr;
+    const bool probe = PROBE && pool.dbg != nullptr;                  // (rt_debug_pass_timing: a build of its own, all arms)
     unsigned long long t_start = 0, t_dry = 0;
     bool dry_seen = false;
     if (probe) t_start = wall_clock64();
@@ -565,8 +568,8 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
-    const int sphere_reps = (int)((node_quorum_u >> 8) & 0xFu) + 1;
-    const int tail_factor = (int)((node_quorum_u >> 12) & 0xFu);      // (0 would mean: stay whenever a node lane exists)
+    constexpr int sphere_reps = 2;                                    // (a span-2 leaf pair in one turn)
+    constexpr int tail_factor = 2;
     const bool keep_pace = ((node_quorum_u >> 28) & 1u) == 0;          // (bit 28 of the tuning word switches the pacing off)
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -576,15 +579,18 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     // each adds its progress through its list to a global sum, compares itself with the mean and sets its waves'
     // s_setprio — behind the field: high, ahead: low. They then arrive together and the chip stays full.
     uint32_t pace_tick = 0, pace_reported = 0;
+    const float pace_scale = (float)kPaceOne / (float)n_list, pace_mean = 1.0f / (float)gridDim.x;
 
     for (;;) {
         if (keep_pace && (pace_tick++ & 63u) == 0) {
             if (tid == 0) {
                 const uint32_t taken = list_next < n_list ? list_next : n_list;
-                const uint32_t f = (uint32_t)(((uint64_t)taken * kPaceOne) / n_list);
-                const uint32_t sum = atomicAdd(pool.pace, f - pace_reported) + (f - pace_reported);
+                uint32_t f = (uint32_t)((float)taken * pace_scale);     // (float is plenty: this steers speed, not results)
+                f = f > kPaceOne ? kPaceOne : f;
+                const uint32_t delta = (uint32_t)__builtin_amdgcn_readfirstlane((int)(f - pace_reported));
+                const uint32_t sum = atomicAdd(pool.pace, delta) + delta;
                 pace_reported = f;
-                const int d = (int)f - (int)(sum / gridDim.x);
+                const int d = (int)f - (int)((float)sum * pace_mean);
                 block_prio = d < -(int)(kPaceOne / 128) ? 3u : d < 0 ? 2u : d < (int)(kPaceOne / 128) ? 1u : 0u;
             }
             switch (block_prio) {                                      // (a stale read is as good: the next one is 64 rounds away)
@@ -656,8 +662,11 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         int best = -1, best_n = 0;
 #pragma unroll
         for (int o = 0; o < (int)OP_COUNT; o++) {
+            if (!(FEAT & kFeatMisc) && o == (int)OP_MISC) continue;
+            if (!(FEAT & kFeatMovers) && o == (int)OP_CTX) continue;
+            if (!(FEAT & kFeatVolumes) && (o == (int)OP_BOX || o == (int)OP_MEDIUM)) continue;
             int n = __popcll(__ballot(L.op == (uint32_t)o));
-            int score = n * (int)((vote_weights >> (4 * o)) & 0xFu);
+            int score = o == (int)OP_NODE ? n : 2 * n;                // a node step outside the fast path yields to everything else
             if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
@@ -721,7 +730,34 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face);
             T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83
-            if (L.top != REF_MED2) {
+            if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM && RT_REF_KIND(s.media[RT_REF_INDEX(L.top)].boundary) == RT_KIND_SPHERE) {
+                // ConstantMedium::hit with a Sphere boundary, constantmedium.rs:49-83 in one go: the two
+                // boundary queries are Sphere::hit (sphere.rs:39-58) on the same sphere with different t_min.
+                const rt_medium &m = s.media[RT_REF_INDEX(L.top)];
+                const rt_sphere &q = s.spheres[RT_REF_INDEX(m.boundary)];
+                const Vec3 center = ld3(q.center);
+                cnt.prim(RT_KIND_MEDIUM);
+                cnt.prim(RT_KIND_SPHERE);
+                double t1, t2 = 0.0;
+                bool both = sphere_t(center, q.radius, L.cur, L.a_len, -rtm::INF, rtm::INF, t1);
+                if (both) {
+                    cnt.prim(RT_KIND_SPHERE);
+                    both = sphere_t(center, q.radius, L.cur, L.a_len, t1 + 0.0001, rtm::INF, t2);
+                }
+                if (both) {
+                    t1 = rtm::fmax_(t1, t_min);
+                    t2 = rtm::fmin_(t2, L.closest);
+                    if (!(t1 >= t2)) {
+                        t1 = rtm::fmax_(t1, 0.0);
+                        double ray_length = L.cur.d.length();
+                        double distance_inside_boundary = (t2 - t1) * ray_length;
+                        double rnd = L.rng.gen_f64();
+                        double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
+                        if (!(hit_distance > distance_inside_boundary)) t_accept(L, t1 + hit_distance / ray_length, 0);   // (L.top is the medium)
+                    }
+                }
+                T_NEXT();
+            } else if (L.top != REF_MED2) {
                 T_SETTLE();                                           // a medium leaf or a finished first query: same steps as inline
             } else if (L.top == REF_MED2) {
                 uint32_t mref = L.med_ref;
@@ -873,9 +909,9 @@ template <bool STATS>
 static void launch_shade(const WfLaunch &w, uint32_t parity) {
     hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
 }
-template <int STACK, bool STATS, unsigned FEAT>
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
 static void launch_trace(const WfLaunch &w) {
-    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT>), dim3(w.blocks / w.pool.segs), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
+    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(w.blocks / w.pool.segs), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
                        w.node_quorum, w.vote_weights, w.stats);
 }
 template <int STACK>
@@ -891,17 +927,20 @@ static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
         default: launch_trace<STACK, false, 7>(w); break;
     }
 }
-static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters) {
+static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters, bool probe) {
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w);
+        else if (probe) launch_trace<kStackSmall, false, 7, true>(w);
         else launch_trace_feat<kStackSmall>(features, w);
     } else if (stack_need <= (uint32_t)kStackMid) {
         if (counters) launch_trace<kStackMid, true, 7>(w);
+        else if (probe) launch_trace<kStackMid, false, 7, true>(w);
         else launch_trace_feat<kStackMid>(features, w);
     } else {
         if (counters) launch_trace<kStackLarge, true, 7>(w);
+        else if (probe) launch_trace<kStackLarge, false, 7, true>(w);
         else launch_trace_feat<kStackLarge>(features, w);
     }
 }
@@ -962,7 +1001,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                 if ((e = hipMemsetAsync(pool.dbg, 0xFF, sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
                 if ((e = hipMemsetAsync(pool.dbg + 1, 0, 4 * sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
             }
-            launch_pass(w[g], iter[g] & 1u, stack_need, features, counters);
+            launch_pass(w[g], iter[g] & 1u, stack_need, features, counters, timing != nullptr);
             iter[g]++;
             iterations++;
         }

@@ -194,7 +194,7 @@ def test_node_step_variants(rt, O):
     # 1. literal step forced on a scene that normally takes the short one
     c, g, s, cam, p = golden_case("final_scene", rt)
     dev = rt.DeviceScene(s.desc)
-    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (2 << 16) | (2 << 20) | (1 << 24) | (1 << 30))
+    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (4 << 16) | (2 << 20) | (1 << 24) | (1 << 30))
     out, st = dev.render(cam, p, g["rows"], want_stats=True)
     assert st.as_dict() == c["counters"] and np.array_equal(bits(out), bits(g["rgb_sum"]))
     assert np.array_equal(bits(dev.render(cam, p, g["rows"])), bits(g["rgb_sum"]))
@@ -255,6 +255,25 @@ def test_node_step_variants(rt, O):
             assert np.array_equal(bits(out), bits(ref)), (label, engine)
             assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), (label, engine)
     assert st_ref.node_visits > 0
+
+
+def test_scheduling_knobs_never_change_results(rt, O):
+    """Segments per traversal workgroup, stream groups, pacing, the timing probe: speed only (rt2022_debug.h)."""
+    def word(q=18, reps=1, tail=2, segs=4, shift=2, groups=1, extra=0):
+        return q | (reps << 8) | (tail << 12) | (segs << 16) | (shift << 20) | (groups << 24) | extra
+    for name in ("final_scene", "cornell_smoke"):
+        c, g, s, cam, p = golden_case(name, rt)
+        dev = rt.DeviceScene(s.desc)
+        for w in (word(segs=1), word(segs=8, groups=3), word(groups=8, shift=0), word(q=64, tail=15, extra=1 << 28),
+                  word(q=1, reps=3, extra=1 << 29), word(segs=3, groups=2, extra=(1 << 28) | (1 << 30))):
+            dev.set_tuning(w)
+            out, st = dev.render(cam, p, g["rows"], want_stats=True)
+            assert st.as_dict() == c["counters"], (name, hex(w))
+            assert np.array_equal(bits(out), bits(g["rgb_sum"])), (name, hex(w))
+            assert np.array_equal(bits(dev.render(cam, p, g["rows"])), bits(g["rgb_sum"])), (name, hex(w))
+            if w & (1 << 29):
+                t = dev.pass_timing()
+                assert t["passes"] > 0 and 0 < t["wave_life_ms"] <= t["span_ms"] and t["wave_dry_ms"] <= t["wave_life_ms"]
 
 
 def test_medium_with_a_composite_boundary(rt, O):
