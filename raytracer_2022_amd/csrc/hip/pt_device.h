@@ -100,6 +100,10 @@ constexpr int kStackSmall = 22;   // 22 KiB of stack + 8 KiB ray list: five work
 constexpr int kStackMid = 30;     // 30 + 8 KiB: four workgroups per CU (million-triangle meshes need ~26 entries)
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
+#ifndef RT2022_TRACE_BLOCKS_PER_CU
+#define RT2022_TRACE_BLOCKS_PER_CU 5
+#endif
+constexpr int kTraceBlocksPerCU = RT2022_TRACE_BLOCKS_PER_CU;   // resident traversal workgroups per CU the lean kernels are built for
 
 // Launchers (pt_kernel.hip). `stack_need` = entries the scene needs (host-computed).
 hipError_t launch_render(const SceneDev &scene, const RenderArgs &args, uint32_t stack_need, bool counters,

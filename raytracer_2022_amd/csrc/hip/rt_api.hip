@@ -380,7 +380,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         uint32_t segs = (sc->node_quorum >> 16) & 0xFu;
         if (segs < 1) segs = 1;
         if (segs > 8) segs = 8;
-        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : 5u * (uint32_t)prop.multiProcessorCount * segs;
+        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : (uint32_t)kTraceBlocksPerCU * (uint32_t)prop.multiProcessorCount * segs;
         // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
         uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
