@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
         p.background[0] = background.x; p.background[1] = background.y; p.background[2] = background.z;
         p.t_min = 0.001; p.seed = SEED; p.n_frames = 1;
         p.n_rows = IMAGE_HEIGHT; p.row_ids = random_line_id.data();
-        p.spp_chunk = 10;   // 0 = the reference's exact running sum per pixel; chunks expose more parallel work items
+        p.spp_chunk = 1;    // one work item per sample: the reference's running sum per pixel bit for bit (like 0), but parallel
         p.flags = 0;
         std::vector<double> output_pixel_color((size_t)IMAGE_WIDTH * IMAGE_HEIGHT * 3);
         rt_stats stats{};

@@ -255,7 +255,9 @@ typedef struct rt_params {
     const uint32_t *row_ids;          /* host pointer (rt_render) or device pointer (rt_render_device) */
     /* 0: each pixel's samples are summed 0..spp in order (main.rs:144-151).
      * k>0: samples are summed in consecutive chunks of k, and the chunk sums
-     * are then added in chunk order — same value to ~1 ulp, finer work items. */
+     * are then added in chunk order — same value to ~1 ulp, finer work items.
+     * k=1 is the reference's order again, bit for bit (0 + L0 + L1 + ...), with
+     * the finest work items: what a throughput-minded caller should pass. */
     uint32_t spp_chunk;
     uint32_t flags;                   /* RT_FLAG_* */
 } rt_params;

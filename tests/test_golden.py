@@ -37,6 +37,17 @@ def test_oracle_thread_count_does_not_change_results(rt, O):
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+def test_one_sample_per_item_is_the_running_sum(rt, O):
+    """spp_chunk = 1 (0 + L0 + L1 + ...) has the bits of spp_chunk = 0, the reference's loop (main.rs:144-151)."""
+    for scene in ("cornell_box", "final_scene"):
+        s = rt.HostScene(scene, seed=4)
+        cam, bg = s.default_view(1.5)
+        rows = np.arange(20, dtype=np.uint32)
+        outs = [O.render_cpu(s.desc, cam, rt.make_params(30, 20, 6, 50, bg, seed=4, spp_chunk=k), rows, n_threads=4) for k in (0, 1, 4)]
+        assert np.array_equal(outs[0].view(np.uint64), outs[1].view(np.uint64)), scene
+        assert np.allclose(outs[0], outs[2], rtol=1e-12, atol=0, equal_nan=True), scene
+
+
 def test_rows_are_independent(rt, O):
     """RNG keyed by (seed, frame, pixel, sample): any row subset gives the same pixels (multi-GPU invariance)."""
     c, g, s, cam, p = load_case("cornell_box", rt)

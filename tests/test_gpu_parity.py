@@ -276,6 +276,19 @@ def test_scheduling_knobs_never_change_results(rt, O):
                 assert t["passes"] > 0 and 0 < t["wave_life_ms"] <= t["span_ms"] and t["wave_dry_ms"] <= t["wave_life_ms"]
 
 
+def test_one_sample_per_item_is_the_running_sum(rt, O):
+    """spp_chunk = 1 adds 0 + L0 + L1 + ... like spp_chunk = 0 (main.rs:144-151): same bits, finest work items."""
+    for scene, W, H, spp in (("cornell_box", 40, 40, 7), ("final_scene", 48, 32, 5)):
+        s = rt.HostScene(scene, seed=9)
+        cam, bg = s.default_view(W / H)
+        rows = rt.shuffled_rows(H, 2)
+        dev = rt.DeviceScene(s.desc)
+        outs = [dev.render(cam, rt.make_params(W, H, spp, 50, bg, seed=9, spp_chunk=k), rows) for k in (0, 1)]
+        assert np.array_equal(bits(outs[0]), bits(outs[1])), scene
+        ref = O.render_cpu(s.desc, cam, rt.make_params(W, H, spp, 50, bg, seed=9, spp_chunk=1), rows, n_threads=4)
+        assert np.array_equal(bits(outs[1]), bits(ref)), scene
+
+
 def test_medium_with_a_composite_boundary(rt, O):
     """ConstantMedium<H> for any H (constantmedium.rs:14-22): a boundary that is a BVH of a box and a sphere.
     The two boundary queries run through the ordinary traversal arms with their own t window."""
