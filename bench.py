@@ -111,7 +111,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (a reduced-spp run is NOT the headline number)")
-    ap.add_argument("--spp-chunk", type=int, default=1)
+    ap.add_argument("--spp-chunk", type=int, default=-1,
+                    help="samples per work item; default: 1 (the reference's summation order) unless the per-sample partial sums "
+                         "would exceed 32 GB of HBM, then the smallest chunk that fits")
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -147,6 +149,9 @@ def main():
     assets = args.assets if os.path.isdir(args.assets) else None
     scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
     cam, bg = scene.default_view(W / H)
+    if args.spp_chunk < 0:
+        per_sample = H * W * 24.0                           # bytes of partial sums per sample index (H rows per GPU)
+        args.spp_chunk = max(1, int(-(-spp * per_sample // 32e9)))
     params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=world, spp_chunk=args.spp_chunk)
     dscene = rt.DeviceScene(scene.desc)
 
