@@ -63,17 +63,17 @@ struct RenderArgs {
 };
 
 // ---- wavefront engine (pt_wavefront.hip) -------------------------------------------
-// A pool of path slots in HBM, structure-of-arrays ([field][slot]); workgroup b owns the
-// slots [b*kSlotsPerBlock, (b+1)*kSlotsPerBlock) for the whole frame.
+// A pool of path slots in HBM, one array of records per field; segment b (= shade workgroup b) owns
+// the slots [b*kSlotsPerBlock, (b+1)*kSlotsPerBlock) for the whole frame.
 constexpr int kSlotsPerBlock = 4096;
 struct WfPool {
     uint32_t n_slots;
-    uint32_t n_blocks;
+    uint32_t n_blocks;      // segments
     uint8_t *kind;          // [P]    what the slot waits for (SlotKind)
     // One 64-byte record per slot: {ox oy oz dx dy dz tm, rng state} — exactly one cache line,
     // so a lane fetches its ray with four 16-byte loads whatever order the slots are visited in.
     double *ray;            // [P][8]
-    // One 32-byte record per slot: {t (f64), leaf ref, box face | movers << 4, 4 mover refs}.
+    // One 32-byte record per slot: {t (f64), leaf ref, box face | movers << 4 | node steps << 16, 4 mover refs}.
     uint32_t *hit;          // [P][8]
     // One 32-byte record per slot: {item = pixel slot * n_chunks + chunk (u64), next sample, end
     // sample, remaining depth, px, py, frame}.
@@ -96,8 +96,8 @@ struct WfPool {
 };
 
 // Traversal-stack capacities the megakernel is instantiated for.
-constexpr int kStackSmall = 22;   // 22 KiB of stack + 8 KiB ray list: five workgroups fit a CU's 160 KiB of LDS
-constexpr int kStackMid = 30;     // 30 + 8 KiB: four workgroups per CU (million-triangle meshes need ~26 entries)
+constexpr int kStackSmall = 22;   // 22 KiB of LDS per workgroup; the lean kernels run five workgroups per CU (VGPR-bound)
+constexpr int kStackMid = 30;     // million-triangle meshes need ~26 entries; built for four workgroups per CU
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
 #ifndef RT2022_TRACE_BLOCKS_PER_CU

@@ -7,18 +7,20 @@
 // (profiles/r1_megakernel_*.txt). Split at "closest hit found", the traversal kernel is
 // lean and the shading kernel is wide, and each gets the occupancy it can use.
 //
-// Paths live in a pool of slots in HBM (WfPool, structure-of-arrays). Workgroup b owns
-// slots [b*4096, (b+1)*4096) for the whole frame, so there are no global queues and no
-// global atomics on the data path:
-//   wf_shade  counting-sorts its slots by what they wait for (miss / light / lambertian /
-//             metal / dielectric / isotropic / fresh) in LDS and shades them in that order —
-//             material dispatch by sorted type id, wave-uniform except at bin boundaries;
+// Paths live in a pool of slots in HBM (WfPool, one record per slot and field). The pool is cut
+// into segments of 4096 slots; a segment belongs to one shade workgroup, four consecutive segments
+// to one trace workgroup, for the whole frame — so there are no global queues, and the only global
+// atomics on the data path are the work counter and the pacing sum:
+//   wf_shade  counting-sorts its slots by what they wait for (miss / light / lambertian by
+//             texture / metal / dielectric / isotropic / fresh) in LDS and shades them in that
+//             order — material dispatch by sorted type id, wave-uniform except at bin boundaries;
 //             finished paths are unwound from the bounce tape, added to their pixel, and
-//             replaced by the next sample / work item at once;
-//   wf_trace  compacts the slots that carry a ray into an LDS list and runs the in-wave
-//             scheduled traversal over it: lanes pull the next ray from the list as soon as
-//             theirs is done (__ballot / __popcll / __shfl refill), and the wave executes the
-//             operation most lanes wait for (node step, sphere test, box, medium, ...).
+//             replaced by the next sample / work item at once; last, it writes the segment's
+//             ray list for the trace pass, longest expected traversal first;
+//   wf_trace  runs the in-wave scheduled traversal over its segments' lists: lanes pull the next
+//             ray as soon as theirs is done (__ballot / __popcll / __shfl refill), the wave executes
+//             the operation most lanes wait for (node step, sphere test, box, medium, ...), and
+//             the workgroups keep pace with each other through s_setprio.
 // The host alternates the two until no slot carries a ray any more.
 //
 // Per-lane semantics never change: every path consumes its RNG stream and visits nodes

@@ -32,7 +32,7 @@ ms = run(dev, cam, pp, rows, W)
 t = dev.pass_timing()
 print('pass timing (probe run %.1f ms): %s' % (ms, t))
 print('  mean wave lifetime / pass span = %.3f   dry tail / lifetime = %.3f' % (t['wave_life_ms'] / t['span_ms'], t['wave_dry_ms'] / t['wave_life_ms']), flush=True)
-cfgs = [('wavefront', b, 1, Q(segs=sg), 0x22222221, None) for b, sg in ((0, 2), (0, 4), (0, 6), (0, 8), (0, 4))]
+cfgs = [('wavefront', b, 1, Q(segs=sg, groups=g), 0x22222221, None) for b, sg, g in ((0, 4, 1), (0, 4, 2), (0, 4, 4), (10240, 4, 2), (10240, 4, 4), (0, 4, 1))]
 for eng, blocks, chunk, q, wts, pc in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
