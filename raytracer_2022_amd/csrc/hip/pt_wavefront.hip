@@ -916,17 +916,17 @@ static void launch_trace(const WfLaunch &w) {
     hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(w.blocks / w.pool.segs), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
                        w.node_quorum, w.vote_weights, w.stats);
 }
-template <int STACK>
+template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
     switch (feat & 7u) {
-        case 0: launch_trace<STACK, false, 0>(w); break;
-        case 1: launch_trace<STACK, false, 1>(w); break;
-        case 2: launch_trace<STACK, false, 2>(w); break;
-        case 3: launch_trace<STACK, false, 3>(w); break;
-        case 4: launch_trace<STACK, false, 4>(w); break;
-        case 5: launch_trace<STACK, false, 5>(w); break;
-        case 6: launch_trace<STACK, false, 6>(w); break;
-        default: launch_trace<STACK, false, 7>(w); break;
+        case 0: launch_trace<STACK, false, 0, PROBE>(w); break;
+        case 1: launch_trace<STACK, false, 1, PROBE>(w); break;
+        case 2: launch_trace<STACK, false, 2, PROBE>(w); break;
+        case 3: launch_trace<STACK, false, 3, PROBE>(w); break;
+        case 4: launch_trace<STACK, false, 4, PROBE>(w); break;
+        case 5: launch_trace<STACK, false, 5, PROBE>(w); break;
+        case 6: launch_trace<STACK, false, 6, PROBE>(w); break;
+        default: launch_trace<STACK, false, 7, PROBE>(w); break;
     }
 }
 static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters, bool probe) {
@@ -934,7 +934,7 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     else launch_shade<false>(w, parity);
     if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w);
-        else if (probe) launch_trace<kStackSmall, false, 7, true>(w);
+        else if (probe) launch_trace_feat<kStackSmall, true>(features, w);   // (the probe exists per feature set for the small stack only)
         else launch_trace_feat<kStackSmall>(features, w);
     } else if (stack_need <= (uint32_t)kStackMid) {
         if (counters) launch_trace<kStackMid, true, 7>(w);
