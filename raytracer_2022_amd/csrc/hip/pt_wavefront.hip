@@ -55,7 +55,7 @@ enum SlotKind : uint32_t {
 };
 
 constexpr int S = kSlotsPerBlock;
-constexpr uint32_t kPaceOne = 32768;       // a workgroup's whole list, in the units of WfPool::pace
+constexpr uint32_t kChunk = 256;           // list entries a wave claims at a time
 
 struct PoolView {
     const WfPool &p;
@@ -425,7 +425,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
         // turns, so each pass can clear the one the next pass will add to.
         if (acc) atomicAdd(&pool.n_active[parity], acc);
-        if (blockIdx.x == 0) { pool.n_active[parity ^ 1u] = 0; *pool.pace = 0; }
+        if (acc) atomicMax(&pool.max_list[parity], acc);
+        if (blockIdx.x == 0) { pool.n_active[parity ^ 1u] = 0; pool.max_list[parity ^ 1u] = 0; *pool.next_chunk = 0; }
     }
     __syncthreads();
 #pragma unroll
@@ -530,34 +531,31 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
 __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 22 || (FEAT & kFeatMisc)) ? 4 : kTraceBlocksPerCU) wf_trace(const SceneDev s, const WfPool pool,
-                                                   const double t_min, const uint32_t node_quorum_u, const uint32_t vote_weights, StatsDev *stats) {
+                                                   const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
     __shared__ uint32_t stack_lds[STACK * kBlock];
-    __shared__ uint32_t seg_end[8];          // running totals of the segments' list lengths
-    __shared__ uint32_t list_next;
-    __shared__ uint32_t block_prio;
     const PoolView pv{pool};
-    const uint32_t seg0 = blockIdx.x * pool.segs;
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
     TStack<STACK> st{stack_lds + tid};
 
-    // The ray lists of this workgroup's segments (written by the shade pass) are worked through back to back.
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t i = 0; i < 8; i++) { if (i < pool.segs) acc += pool.list_n[seg0 + i]; seg_end[i] = acc; }
-        list_next = 0;
-        block_prio = 1;
-    }
-    __syncthreads();
-    const uint32_t n_list = seg_end[7];
-    if (n_list == 0) {
-        if (tid == 0) atomicAdd(pool.pace, kPaceOne);
-        return;
-    }
+    // Work of a pass = the ray lists of all segments (written by the preceding shade pass), cut into chunks of
+    // kChunk entries and numbered slice-major: chunk id -> (slice = id / segments, segment = id % segments), so
+    // that the counter hands out every segment's longest rays first. Each wave takes chunks from one global
+    // counter as it runs dry — the waves, workgroups and CUs of the persistent grid therefore all finish within
+    // one chunk of each other however unevenly they advance. (Bound statically to its segments, a workgroup's
+    // speed depended on its CU and on its dispatch order within the CU — the arbiter serves the oldest wave
+    // first — and a pass waited 10-25 % of its time for the slowest: rt_debug_pass_timing)
+    const uint32_t n_seg = pool.n_blocks;
+    const uint32_t total_ids = ((pool.max_list[parity] + kChunk - 1u) / kChunk) * n_seg;
+    // This wave's chunk — entries [base + taken, base + n) of pool.list — and "the counter has run out": per-wave
+    // state, kept in LDS rather than in four more live registers (the kernel has none to spare).
+    __shared__ uint32_t chunk_lds[kBlock / 64][4];
+    uint32_t *const cs = chunk_lds[tid >> 6];
+    if (lane < 4) cs[lane] = 0;
     const bool probe = PROBE && pool.dbg != nullptr;                  // (rt_debug_pass_timing: a build of its own, all arms)
     unsigned long long t_start = 0, t_dry = 0;
     bool dry_seen = false;
@@ -572,36 +570,10 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
     constexpr int sphere_reps = 2;                                    // (a span-2 leaf pair in one turn)
     constexpr int tail_factor = 2;
-    const bool keep_pace = ((node_quorum_u >> 28) & 1u) == 0;          // (bit 28 of the tuning word switches the pacing off)
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // Issue priority. The SIMD's arbiter serves its oldest wave first, and the five workgroups of a CU start a
-    // pass together: measured, the first-dispatched fifth of the grid finished at 3.8 ms and the last at 5.3 ms,
-    // the SIMDs running ever emptier in between. So the workgroups keep pace with each other: every 64 rounds
-    // each adds its progress through its list to a global sum, compares itself with the mean and sets its waves'
-    // s_setprio — behind the field: high, ahead: low. They then arrive together and the chip stays full.
-    uint32_t pace_tick = 0, pace_reported = 0;
-    const float pace_scale = (float)kPaceOne / (float)n_list, pace_mean = 1.0f / (float)gridDim.x;
 
     for (;;) {
-        if (keep_pace && (pace_tick++ & 63u) == 0) {
-            if (tid == 0) {
-                const uint32_t taken = list_next < n_list ? list_next : n_list;
-                uint32_t f = (uint32_t)((float)taken * pace_scale);     // (float is plenty: this steers speed, not results)
-                f = f > kPaceOne ? kPaceOne : f;
-                const uint32_t delta = (uint32_t)__builtin_amdgcn_readfirstlane((int)(f - pace_reported));
-                const uint32_t sum = atomicAdd(pool.pace, delta) + delta;
-                pace_reported = f;
-                const int d = (int)f - (int)((float)sum * pace_mean);
-                block_prio = d < -(int)(kPaceOne / 128) ? 3u : d < 0 ? 2u : d < (int)(kPaceOne / 128) ? 1u : 0u;
-            }
-            switch (block_prio) {                                      // (a stale read is as good: the next one is 64 rounds away)
-                case 3: __builtin_amdgcn_s_setprio(3); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                default: __builtin_amdgcn_s_setprio(0); break;
-            }
-        }
         // Fast path: keep stepping nodes while enough lanes want to.
         for (;;) {
             bool isn = L.op == OP_NODE && L.plain;
@@ -836,19 +808,38 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
-            unsigned long long m = __ballot(true);
-            int leader = __ffsll((long long)m) - 1;
-            uint32_t wbase = 0;
-            if ((int)lane == leader) wbase = atomicAdd(&list_next, (uint32_t)__popcll(m));
-            wbase = __shfl(wbase, leader);
-            uint32_t mine = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (probe && !dry_seen && __ballot(mine >= n_list)) { dry_seen = true; t_dry = wall_clock64(); }
-            if (mine < n_list) {
-                uint32_t seg = 0, start = 0;
-#pragma unroll
-                for (int i = 0; i < 7; i++) { uint32_t e = seg_end[i]; bool ge = mine >= e; seg += ge ? 1u : 0u; start = ge ? e : start; }
-                const uint32_t sbase = (seg0 + seg) * (uint32_t)S;
-                L.slot = sbase + pool.list[sbase + (mine - start)];
+            const unsigned long long m = __ballot(true);
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t need = (uint32_t)__popcll(m);
+            uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            uint32_t entry_idx = 0xFFFFFFFFu;                         // index into pool.list of the entry this lane takes
+            uint32_t ch_base = cs[0], ch_n = cs[1], ch_taken = cs[2];
+            bool drained = cs[3] != 0;
+            for (;;) {
+                const uint32_t avail = ch_n - ch_taken;
+                if (entry_idx == 0xFFFFFFFFu) {
+                    if (rank < avail) entry_idx = ch_base + ch_taken + rank;
+                    else rank -= avail;
+                }
+                const uint32_t take = need < avail ? need : avail;
+                ch_taken += take;
+                need -= take;
+                if (need == 0 || drained) break;
+                uint32_t id = 0;                                      // next chunk
+                if ((int)lane == leader) id = atomicAdd(pool.next_chunk, 1u);
+                id = (uint32_t)__shfl((int)id, leader);
+                if (id >= total_ids) { drained = true; break; }
+                const uint32_t slice = id / n_seg, seg = id - slice * n_seg, first = slice * kChunk;
+                const uint32_t n = pool.list_n[seg];
+                ch_n = n > first ? (n - first < kChunk ? n - first : kChunk) : 0u;
+                ch_base = seg * (uint32_t)S + first;
+                ch_taken = 0;
+            }
+            if ((int)lane == leader) { cs[0] = ch_base; cs[1] = ch_n; cs[2] = ch_taken; cs[3] = drained ? 1u : 0u; }
+            if (probe && !dry_seen && drained) { dry_seen = true; t_dry = wall_clock64(); }
+            if (entry_idx != 0xFFFFFFFFu) {
+                const uint32_t sbase = entry_idx & ~((uint32_t)S - 1u);
+                L.slot = sbase + pool.list[entry_idx];
                 uint64_t rs;
                 Ray wr = pv.load_ray(L.slot, rs);
                 L.tm = wr.tm;
@@ -868,7 +859,6 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             }
         }
     }
-    if (tid == 0) atomicAdd(pool.pace, kPaceOne - pace_reported);       // (wave 0 leaving: the others are at the list's end too)
     if (probe && lane == 0) {
         unsigned long long t_end = wall_clock64();
         atomicMin(&pool.dbg[0], t_start);
@@ -912,38 +902,44 @@ static void launch_shade(const WfLaunch &w, uint32_t parity) {
     hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
 }
 template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
-static void launch_trace(const WfLaunch &w) {
-    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(w.blocks / w.pool.segs), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
-                       w.node_quorum, w.vote_weights, w.stats);
+static void launch_trace(const WfLaunch &w, uint32_t parity) {
+    // A persistent grid: as many workgroups as the kernel's launch bounds keep resident, never more than the work
+    // (a segment holds at most 4096 / kChunk chunks for the 4 waves of a workgroup).
+    constexpr uint32_t per_cu = STACK > 32 ? 2 : STATS ? 3 : (STACK > 22 || (FEAT & kFeatMisc)) ? 4 : kTraceBlocksPerCU;
+    uint32_t grid = per_cu * (w.pool.n_cus ? w.pool.n_cus : 1u);
+    const uint32_t most = w.blocks * ((uint32_t)S / kChunk / 4u);
+    if (grid > most) grid = most;
+    hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(grid), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
+                       w.node_quorum, parity, w.stats);
 }
 template <int STACK, bool PROBE = false>
-static void launch_trace_feat(unsigned feat, const WfLaunch &w) {
+static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
     switch (feat & 7u) {
-        case 0: launch_trace<STACK, false, 0, PROBE>(w); break;
-        case 1: launch_trace<STACK, false, 1, PROBE>(w); break;
-        case 2: launch_trace<STACK, false, 2, PROBE>(w); break;
-        case 3: launch_trace<STACK, false, 3, PROBE>(w); break;
-        case 4: launch_trace<STACK, false, 4, PROBE>(w); break;
-        case 5: launch_trace<STACK, false, 5, PROBE>(w); break;
-        case 6: launch_trace<STACK, false, 6, PROBE>(w); break;
-        default: launch_trace<STACK, false, 7, PROBE>(w); break;
+        case 0: launch_trace<STACK, false, 0, PROBE>(w, parity); break;
+        case 1: launch_trace<STACK, false, 1, PROBE>(w, parity); break;
+        case 2: launch_trace<STACK, false, 2, PROBE>(w, parity); break;
+        case 3: launch_trace<STACK, false, 3, PROBE>(w, parity); break;
+        case 4: launch_trace<STACK, false, 4, PROBE>(w, parity); break;
+        case 5: launch_trace<STACK, false, 5, PROBE>(w, parity); break;
+        case 6: launch_trace<STACK, false, 6, PROBE>(w, parity); break;
+        default: launch_trace<STACK, false, 7, PROBE>(w, parity); break;
     }
 }
 static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters, bool probe) {
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (stack_need <= (uint32_t)kStackSmall) {
-        if (counters) launch_trace<kStackSmall, true, 7>(w);
-        else if (probe) launch_trace_feat<kStackSmall, true>(features, w);   // (the probe exists per feature set for the small stack only)
-        else launch_trace_feat<kStackSmall>(features, w);
+        if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
+        else if (probe) launch_trace_feat<kStackSmall, true>(features, w, parity);   // (the probe exists per feature set for the small stack only)
+        else launch_trace_feat<kStackSmall>(features, w, parity);
     } else if (stack_need <= (uint32_t)kStackMid) {
-        if (counters) launch_trace<kStackMid, true, 7>(w);
-        else if (probe) launch_trace<kStackMid, false, 7, true>(w);
-        else launch_trace_feat<kStackMid>(features, w);
+        if (counters) launch_trace<kStackMid, true, 7>(w, parity);
+        else if (probe) launch_trace<kStackMid, false, 7, true>(w, parity);
+        else launch_trace_feat<kStackMid>(features, w, parity);
     } else {
-        if (counters) launch_trace<kStackLarge, true, 7>(w);
-        else if (probe) launch_trace<kStackLarge, false, 7, true>(w);
-        else launch_trace_feat<kStackLarge>(features, w);
+        if (counters) launch_trace<kStackLarge, true, 7>(w, parity);
+        else if (probe) launch_trace<kStackLarge, false, 7, true>(w, parity);
+        else launch_trace_feat<kStackLarge>(features, w, parity);
     }
 }
 
@@ -966,6 +962,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, pool.cam_steps, n, used);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(pool.max_list, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
     }
     const uint32_t trace_blocks = blocks / pool.segs;
     int G = timing ? 1 : gs.n;
@@ -984,7 +981,8 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         v.kind += off; v.ray += off * 8; v.hit += off * 8; v.state += off * 8; v.pixel_sum += off * 4;
         v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin; v.cam_steps += off;
         v.n_active = pool.n_active + 2 * g;
-        v.pace = pool.pace + g;
+        v.next_chunk = pool.next_chunk + g;
+        v.max_list = pool.max_list + 2 * g;
         w[g] = WfLaunch{scene, v, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, n_segs, G == 1 ? stream : gs.stream[g]};
     }
     if (G > 1) {                                // the groups start after what the caller's stream holds so far
@@ -1035,7 +1033,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                     timing[3] += 1.0;
                     timing[4] += (double)h[4];
                     if (getenv("RT2022_PASS_LOG") && (iter[g] == 50 || iter[g] == 51 || iter[g] == 80)) {      // wave 0 of every workgroup
-                        const uint32_t nb = w[g].blocks / w[g].pool.segs;
+                        const uint32_t nb = (uint32_t)(h[4] / 4);                 // (workgroups of the persistent grid that ran)
                         std::vector<unsigned long long> bt(2 * nb);
                         if (hipMemcpy(bt.data(), pool.dbg + 8, bt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
                             std::vector<double> st_, en_;

@@ -327,7 +327,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.list_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
     q.cam_steps = pool_alloc<uint16_t>(w, P);
     q.n_active = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
-    q.pace = pool_alloc<uint32_t>(w, kMaxGroups);
+    q.next_chunk = pool_alloc<uint32_t>(w, kMaxGroups);
+    q.max_list = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
     w.pool_dbg = pool_alloc<unsigned long long>(w, 8 + 2 * 65536);
     w.pool_slots = slots;
     w.pool_depth = depth;
@@ -388,6 +389,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
         w.pool.segs = segs;
+        w.pool.n_cus = (uint32_t)prop.multiProcessorCount;
         const bool timing = (sc->node_quorum & (1u << 29)) != 0;
         w.gs.n = (int)((sc->node_quorum >> 24) & 0xFu);     // groups of segments passing independently (streams)
         if (w.gs.n < 1) w.gs.n = 1;
