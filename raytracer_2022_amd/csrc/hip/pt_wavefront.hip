@@ -55,7 +55,10 @@ enum SlotKind : uint32_t {
 };
 
 constexpr int S = kSlotsPerBlock;
-constexpr uint32_t kChunk = 256;           // list entries a wave claims at a time
+#ifndef RT2022_CHUNK
+#define RT2022_CHUNK 256
+#endif
+constexpr uint32_t kChunk = RT2022_CHUNK;           // list entries a wave claims at a time
 
 struct PoolView {
     const WfPool &p;

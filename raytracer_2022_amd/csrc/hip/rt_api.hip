@@ -249,7 +249,7 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (4u << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; 4 segments per trace workgroup; list classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (6u << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 6 segments per resident trace workgroup; list classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
@@ -375,9 +375,10 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Wavefront engine: pool of path slots, shade / trace passes until it drains.
         hipDeviceProp_t prop;
         RT_HIP(hipGetDeviceProperties(&prop, sc->device));
-        // Pool = segments of 4096 path slots (one shade workgroup each); a trace workgroup works through
-        // `segs` of them — the more rays a wave sees per pass, the smaller the share of its under-filled tail.
-        // Five trace workgroups per CU are resident at a time.
+        // Pool = segments of 4096 path slots (one shade workgroup each). The trace pass is a persistent grid of
+        // kTraceBlocksPerCU workgroups per CU that draws on all segments' ray lists; the pool holds `segs` segments
+        // per such workgroup (default 6: 31 M slots, ~58 GB with a depth-50 tape — measured optimum of 2.5-10 K
+        // segments on the headline scene; sized for 288 GB of HBM).
         uint32_t segs = (sc->node_quorum >> 16) & 0xFu;
         if (segs < 1) segs = 1;
         if (segs > 8) segs = 8;
@@ -385,6 +386,9 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
         uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+        // (deep paths: keep the bounce tape under 56 GB by taking fewer segments)
+        const uint64_t tape_per_block = (uint64_t)kSlotsPerBlock * (p->max_depth ? p->max_depth : 1) * 4 * sizeof(double);
+        while (blocks > segs && (uint64_t)blocks * tape_per_block > (56ull << 30)) blocks -= segs;
         if (blocks < segs) segs = blocks;
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);

@@ -194,7 +194,7 @@ def test_node_step_variants(rt, O):
     # 1. literal step forced on a scene that normally takes the short one
     c, g, s, cam, p = golden_case("final_scene", rt)
     dev = rt.DeviceScene(s.desc)
-    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (4 << 16) | (2 << 20) | (1 << 24) | (1 << 30))
+    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (6 << 16) | (2 << 20) | (1 << 24) | (1 << 30))
     out, st = dev.render(cam, p, g["rows"], want_stats=True)
     assert st.as_dict() == c["counters"] and np.array_equal(bits(out), bits(g["rgb_sum"]))
     assert np.array_equal(bits(dev.render(cam, p, g["rows"])), bits(g["rgb_sum"]))

@@ -24,7 +24,7 @@ rays = st.rays * (spp / min(spp, 20))      # (estimate: the counter pass runs at
 print('rays', rays, flush=True)
 for k, v in dev.census().items():
     print('  census %-10s rounds %12d lanes %14d util %.3f' % (k, v[0], v[1], v[2]))
-def Q(q=18, reps=1, tail=2, segs=4, shift=2, groups=1):
+def Q(q=18, reps=1, tail=2, segs=6, shift=2, groups=1):
     return q | (reps << 8) | (tail << 12) | (segs << 16) | (shift << 20) | (groups << 24)
 dev.set_tuning(Q() | (1 << 29))
 pp = rt.make_params(W, H, min(spp, 200), 50, bg, seed=2022, spp_chunk=1)
@@ -32,7 +32,7 @@ ms = run(dev, cam, pp, rows, W)
 t = dev.pass_timing()
 print('pass timing (probe run %.1f ms): %s' % (ms, t))
 print('  mean wave lifetime / pass span = %.3f   dry tail / lifetime = %.3f' % (t['wave_life_ms'] / t['span_ms'], t['wave_dry_ms'] / t['wave_life_ms']), flush=True)
-cfgs = [('wavefront', b, 1, Q(segs=sg, groups=g), 0x22222221, None) for b, sg, g in ((0, 4, 1), (0, 4, 2), (0, 4, 4), (10240, 4, 2), (10240, 4, 4), (0, 4, 1))]
+cfgs = [('wavefront', b, 1, Q(), 0x22222221, None) for b in (0, 2560, 3840, 7680, 10240, 0)]
 for eng, blocks, chunk, q, wts, pc in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
