@@ -15,21 +15,23 @@ extern "C" {
 int rt_debug_math_device(int op, const double *a, const double *b, double *out, uint64_t n);
 /* n draws from Rng(state): mode 0 next_u64, 1 gen_f64 (bits), 2 gen_range(lo,hi) (bits), 3 gen_index(bound). */
 int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n);
-/* Scheduler knobs of the traversal kernels. node_quorum: bits 0-7 = lanes that must want a BVH-node
- * step before the wave takes the node fast path without a vote (1..64); bits 8-11 = extra sphere tests
- * a lane may take in one turn; bits 12-15 = f: below the quorum the fast path still goes on while the
- * node lanes outnumber f x all other pending lanes; bits 16-19 = segments of 4096 path slots a
- * traversal workgroup works through per pass (1..8); bits 20-23 = s: each workgroup's ray list is
- * ordered longest-first by (node steps of the path's previous ray) >> s, 0 = slot order; bits 24-27 = groups the
- * pool is cut into, each alternating its passes on a stream of its own (1..8); bit 28 = do not
- * pace the workgroups' issue priority; bit 29 = run
- * the pass-timing probe (rt_debug_pass_timing); bit 30 = take
- * the literal AABB step only (test hook). vote_weights: 4 bits per
- * operation label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label
- * with the largest lanes * weight. They affect speed only, never results. */
+/* Scheduler knobs of the engines. node_quorum, a bit field:
+ *   0-7   lanes that must want a BVH-node step before the wave takes the node fast path without a
+ *         vote (1..64);
+ *   8-15  (unused: two sphere tests per turn and a tail factor of 2 are built in);
+ *   16-19 pool size of the wavefront engine: segments of 4096 path slots per resident traversal
+ *         workgroup (1..8, default 6);
+ *   20-23 s: every segment's ray list is ordered longest-first by (expected node steps) >> s, 0 = slot order;
+ *   24-27 groups the pool is cut into, each alternating its passes on a stream of its own (1..8, default 1);
+ *   28    (unused);
+ *   29    run the pass-timing probe (rt_debug_pass_timing);
+ *   30    take the literal AABB step only (test hook).
+ * vote_weights (megakernel only; the wavefront engine uses node 1, others 2): 4 bits per operation
+ * label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label with the largest
+ * lanes * weight. All of this affects speed only, never results. */
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights);
 /* Engine behind rt_render*: 1 (default) = wavefront passes (pt_wavefront.hip), 0 = the single
- * megakernel (pt_kernel.hip). max_pool_blocks: workgroups of 4096 path slots (0 = 4 per CU).
+ * megakernel (pt_kernel.hip). max_pool_blocks: segments of 4096 path slots in the pool (0 = the default of the tuning word).
  * Results are bit-identical between the two; only speed differs. */
 int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks);
 /* Scheduler census of the last counter run (RT_FLAG_COUNTERS) of the wavefront traversal kernel:

@@ -8,19 +8,19 @@
 // lean and the shading kernel is wide, and each gets the occupancy it can use.
 //
 // Paths live in a pool of slots in HBM (WfPool, one record per slot and field). The pool is cut
-// into segments of 4096 slots; a segment belongs to one shade workgroup, four consecutive segments
-// to one trace workgroup, for the whole frame — so there are no global queues, and the only global
-// atomics on the data path are the work counter and the pacing sum:
+// into segments of 4096 slots; a segment belongs to one shade workgroup for the whole frame; the trace
+// pass is a persistent grid whose waves draw chunks of the segments' ray lists — so the only global
+// atomics on the data path are the work counter (items) and the chunk counter (ray lists):
 //   wf_shade  counting-sorts its slots by what they wait for (miss / light / lambertian by
 //             texture / metal / dielectric / isotropic / fresh) in LDS and shades them in that
 //             order — material dispatch by sorted type id, wave-uniform except at bin boundaries;
 //             finished paths are unwound from the bounce tape, added to their pixel, and
 //             replaced by the next sample / work item at once; last, it writes the segment's
 //             ray list for the trace pass, longest expected traversal first;
-//   wf_trace  runs the in-wave scheduled traversal over its segments' lists: lanes pull the next
-//             ray as soon as theirs is done (__ballot / __popcll / __shfl refill), the wave executes
-//             the operation most lanes wait for (node step, sphere test, box, medium, ...), and
-//             the workgroups keep pace with each other through s_setprio.
+//   wf_trace  runs the in-wave scheduled traversal over the lists: a wave claims 256 entries at a
+//             time, its lanes pull the next ray as soon as theirs is done (__ballot / __popcll
+//             refill), and the wave executes the operation most lanes wait for (node step, sphere
+//             test, box, medium, ...).
 // The host alternates the two until no slot carries a ray any more.
 //
 // Per-lane semantics never change: every path consumes its RNG stream and visits nodes
