@@ -58,6 +58,10 @@ constexpr int S = kSlotsPerBlock;
 #ifndef RT2022_CHUNK
 #define RT2022_CHUNK 256
 #endif
+#ifndef RT2022_LIST_OCTANTS
+#define RT2022_LIST_OCTANTS 1
+#endif
+constexpr uint32_t kListBins = 16 * 8;     // list order: 16 classes of expected length x 8 direction octants
 constexpr uint32_t kChunk = RT2022_CHUNK;           // list entries a wave claims at a time
 
 struct PoolView {
@@ -175,7 +179,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __shared__ uint32_t sorted[S];
     __shared__ uint32_t n_sorted;
     __shared__ uint8_t new_kind[S];      // the slots' next state (| list class << 4), written back in one coalesced sweep
-    __shared__ uint32_t bins[16];
+    __shared__ uint32_t bins[kListBins];
+    __shared__ uint8_t new_oct[S];       // direction octant of the slot's next ray (second sort key of the list)
     const RenderArgs &a = *ap;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
@@ -399,11 +404,12 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 store_state(pool, slot, stt);
                 uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
                 new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
+                new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
             }
         }
     }
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
-    if (tid < 16) bins[tid] = 0;
+    if (tid < kListBins) bins[tid] = 0;
     __syncthreads();
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(new_kind);
@@ -416,14 +422,16 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t e = new_kind[i * kBlock + tid];
-        uint32_t key = 16;                                             // carries no ray
-        if ((e & 0xFu) == SK_TRACE) { key = 15u - (e >> 4); atomicAdd(&bins[key], 1u); }
+        uint32_t key = kListBins;                                      // carries no ray
+        // (second key: rays that point into the same octant meet the boxes in a similar pattern, and the lanes of a
+        // wave draw neighbouring list entries)
+        if ((e & 0xFu) == SK_TRACE) { key = (15u - (e >> 4)) * 8u + new_oct[i * kBlock + tid]; atomicAdd(&bins[key], 1u); }
         my_key[i] = key;
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
-        for (int k = 0; k < 16; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
+        for (int k = 0; k < (int)kListBins; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
         pool.list_n[blockIdx.x] = acc;
         // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
         // turns, so each pass can clear the one the next pass will add to.
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++)
-        if (my_key[i] < 16) pool.list[base + atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
+        if (my_key[i] < kListBins) pool.list[base + atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
     if (STATS) cnt.flush_wave(a.stats);
 }
 
