@@ -65,7 +65,10 @@ struct RenderArgs {
 // ---- wavefront engine (pt_wavefront.hip) -------------------------------------------
 // A pool of path slots in HBM, one array of records per field; segment b (= shade workgroup b) owns
 // the slots [b*kSlotsPerBlock, (b+1)*kSlotsPerBlock) for the whole frame.
-constexpr int kSlotsPerBlock = 4096;
+#ifndef RT2022_SLOTS_PER_SEGMENT
+#define RT2022_SLOTS_PER_SEGMENT 4096
+#endif
+constexpr int kSlotsPerBlock = RT2022_SLOTS_PER_SEGMENT;     // (a multiple of 256, at most 32768: list entries are u16)
 struct WfPool {
     uint32_t n_slots;
     uint32_t n_blocks;      // segments

@@ -249,7 +249,7 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | (6u << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 6 segments per resident trace workgroup; list classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(6 * 4096 / kSlotsPerBlock > 0 ? 6 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 6 segments per resident trace workgroup; list classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
