@@ -389,6 +389,15 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // (deep paths: keep the bounce tape under 56 GB by taking fewer segments)
         const uint64_t tape_per_block = (uint64_t)kSlotsPerBlock * (p->max_depth ? p->max_depth : 1) * 4 * sizeof(double);
         while (blocks > segs && (uint64_t)blocks * tape_per_block > (56ull << 30)) blocks -= segs;
+        // (and never plan for more than 60 % of the memory that is free right now: other scenes, other users of the GPU)
+        if ((uint64_t)blocks * kSlotsPerBlock > w.pool_slots) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t per_block = (uint64_t)kSlotsPerBlock * 176 + tape_per_block;      // records + tape, bytes
+                const uint64_t budget = (uint64_t)((double)free_b * 0.6) + (uint64_t)w.pool_slots / kSlotsPerBlock * per_block;
+                while (blocks > segs && (uint64_t)blocks * per_block > budget) blocks -= segs;
+            }
+        }
         if (blocks < segs) segs = blocks;
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
