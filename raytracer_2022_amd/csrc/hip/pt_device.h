@@ -63,6 +63,28 @@ struct RenderArgs {
 };
 
 // ---- wavefront engine (pt_wavefront.hip) -------------------------------------------
+// What a path slot waits for.
+enum SlotKind : uint32_t {
+    SK_IDLE = 0,        // nothing left to do
+    SK_FRESH = 1,       // no path yet: start the first sample
+    SK_TRACE = 2,       // carries a ray: world.hit pending
+    SK_MISS = 3,
+    SK_LIGHT = 4,
+    // Lambertian by albedo texture: a wave that holds one noise-textured hit pays seven octaves of
+    // Perlin for all 64 lanes, so the texture kind is part of the sort key.
+    SK_LAMB_SOLID = 5,
+    SK_LAMB_CHECKER = 6,
+    SK_LAMB_NOISE = 7,
+    SK_LAMB_IMAGE = 8,
+    SK_METAL = 9,
+    SK_DIELECTRIC = 10,
+    SK_ISOTROPIC = 11,
+    SK_COUNT = 12
+};
+
+// `mat` of the device copies of the primitive pools = material index | slot kind of a hit on it << kMatKindShift.
+constexpr uint32_t kMatKindShift = 24, kMatIndexMask = (1u << kMatKindShift) - 1u;
+
 // A pool of path slots in HBM, one array of records per field; segment b (= shade workgroup b) owns
 // the slots [b*kSlotsPerBlock, (b+1)*kSlotsPerBlock) for the whole frame.
 #ifndef RT2022_SLOTS_PER_SEGMENT

@@ -234,7 +234,7 @@ RT_DEV void op_shade(const SceneDev &s, const RenderArgs &a, Lane &L, Stack<STAC
         } else {
             HitRec rec;
             winner_record(s, L.r, L.win, rec);
-            const rt_material &mat = s.materials[rec.mat];
+            const rt_material &mat = s.materials[rec.mat & kMatIndexMask];
             uint32_t mk = mat.kind;
             if (mk == RT_MAT_DIFFUSE_LIGHT) {                     // emitted; scatter = None (mod.rs:16-18,174-180)
                 Lterm = rec.front_face ? texture_value(s, mat.tex, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);

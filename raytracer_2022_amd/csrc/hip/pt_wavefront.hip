@@ -36,24 +36,6 @@ namespace rt2022 {
 
 namespace {
 
-enum SlotKind : uint32_t {
-    SK_IDLE = 0,        // nothing left to do
-    SK_FRESH = 1,       // no path yet: start the first sample
-    SK_TRACE = 2,       // carries a ray: world.hit pending
-    SK_MISS = 3,
-    SK_LIGHT = 4,
-    // Lambertian by albedo texture: a wave that holds one noise-textured hit pays seven octaves of
-    // Perlin for all 64 lanes, so the texture kind is part of the sort key.
-    SK_LAMB_SOLID = 5,
-    SK_LAMB_CHECKER = 6,
-    SK_LAMB_NOISE = 7,
-    SK_LAMB_IMAGE = 8,
-    SK_METAL = 9,
-    SK_DIELECTRIC = 10,
-    SK_ISOTROPIC = 11,
-    SK_COUNT = 12
-};
-
 constexpr int S = kSlotsPerBlock;
 #ifndef RT2022_CHUNK
 #define RT2022_CHUNK 256
@@ -154,7 +136,9 @@ RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st) {
     q[1] = make_uint4(st.depth, st.px, st.py, st.frame);
 }
 
-RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
+// The device copies of the primitive pools carry, above the material index, the slot kind a hit on the primitive
+// leads to (kMatKindShift; rt_scene_create): publishing a winner then costs one dependent load, not three.
+RT_DEV uint32_t leaf_material_word(const SceneDev &s, uint32_t leaf) {
     uint32_t idx = RT_REF_INDEX(leaf);
     switch (RT_REF_KIND(leaf)) {
         case RT_KIND_SPHERE: return s.spheres[idx].mat;
@@ -166,6 +150,8 @@ RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) {
         default: return s.media[idx].mat;
     }
 }
+
+RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) { return leaf_material_word(s, leaf) & kMatIndexMask; }
 
 } // namespace
 
@@ -809,11 +795,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 if (!found) pv.store_miss(slot, steps16);
                 if (found) {
                     pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain);
-                    const rt_material &wm = s.materials[leaf_material(s, L.win_leaf)];
-                    uint32_t mk = wm.kind;
-                    kind = mk == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : mk == RT_MAT_METAL ? SK_METAL
-                         : mk == RT_MAT_DIELECTRIC ? SK_DIELECTRIC : mk == RT_MAT_ISOTROPIC ? SK_ISOTROPIC : SK_LAMB_SOLID;
-                    if (mk == RT_MAT_LAMBERTIAN) kind = SK_LAMB_SOLID + s.textures[wm.tex].kind;   // SOLID, CHECKER, NOISE, IMAGE
+                    kind = leaf_material_word(s, L.win_leaf) >> kMatKindShift;
                 }
                 pool.kind[slot] = (uint8_t)kind;
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../../include/rt2022.h"
@@ -499,13 +500,26 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             RT_HIP(hipGetDevice(&sc->device));
             SceneDev &s = sc->dev;
             s.nodes = upload(desc->nodes, desc->n_nodes, sc->owned);
-            s.spheres = upload(desc->spheres, desc->n_spheres, sc->owned);
-            s.moving_spheres = upload(desc->moving_spheres, desc->n_moving_spheres, sc->owned);
-            s.rects = upload(desc->rects, desc->n_rects, sc->owned);
-            s.boxes = upload(desc->boxes, desc->n_boxes, sc->owned);
-            s.triangles = upload(desc->triangles, desc->n_triangles, sc->owned);
-            s.rings = upload(desc->rings, desc->n_rings, sc->owned);
-            s.media = upload(desc->media, desc->n_media, sc->owned);
+            // Primitive pools go up with the slot kind of their material packed above the material index (pt_device.h).
+            RT_REQUIRE(desc->n_materials <= kMatIndexMask, RT_ERR_UNSUPPORTED, "more than 2^24 materials");
+            auto packed = [&](auto *src, uint64_t n) {
+                using T = std::remove_const_t<std::remove_pointer_t<decltype(src)>>;
+                std::vector<T> v(src, src + n);
+                for (T &q : v) {
+                    const rt_material &m = desc->materials[q.mat];
+                    uint32_t sk = m.kind == RT_MAT_DIFFUSE_LIGHT ? SK_LIGHT : m.kind == RT_MAT_METAL ? SK_METAL : m.kind == RT_MAT_DIELECTRIC ? SK_DIELECTRIC
+                                : m.kind == RT_MAT_ISOTROPIC ? SK_ISOTROPIC : (uint32_t)SK_LAMB_SOLID + desc->textures[m.tex].kind;
+                    q.mat |= sk << kMatKindShift;
+                }
+                return upload(v.data(), n, sc->owned);
+            };
+            s.spheres = packed(desc->spheres, desc->n_spheres);
+            s.moving_spheres = packed(desc->moving_spheres, desc->n_moving_spheres);
+            s.rects = packed(desc->rects, desc->n_rects);
+            s.boxes = packed(desc->boxes, desc->n_boxes);
+            s.triangles = packed(desc->triangles, desc->n_triangles);
+            s.rings = packed(desc->rings, desc->n_rings);
+            s.media = packed(desc->media, desc->n_media);
             s.xforms = upload(desc->xforms, desc->n_xforms, sc->owned);
             s.lists = upload(desc->lists, desc->n_lists, sc->owned);
             s.list_items = upload(desc->list_items, desc->n_list_items, sc->owned);
