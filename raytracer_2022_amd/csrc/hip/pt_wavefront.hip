@@ -244,7 +244,9 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 const rt_material &mat = s.materials[leaf_material(s, w.leaf)];
                 bool want_uv = false;
                 const bool lambertian = kind >= SK_LAMB_SOLID && kind <= SK_LAMB_IMAGE;
-                if (kind == SK_LIGHT || lambertian || kind == SK_ISOTROPIC) {
+                if (lambertian) {                                     // (the slot kind says which texture it is)
+                    want_uv = kind == SK_LAMB_IMAGE || kind == SK_LAMB_CHECKER;
+                } else if (kind == SK_LIGHT || kind == SK_ISOTROPIC) {
                     uint32_t tk = s.textures[mat.tex].kind;
                     want_uv = tk == RT_TEX_IMAGE || tk == RT_TEX_CHECKER;
                 }
