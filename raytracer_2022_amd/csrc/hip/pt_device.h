@@ -112,7 +112,6 @@ struct WfPool {
     uint16_t *list;         // [P]
     uint32_t *list_n;       // [n_blocks]
     uint32_t segs;          // segments per trace workgroup (n_blocks is a multiple of it)
-    uint16_t *cam_steps;    // [P] node steps of the slot's latest camera ray: predicts the next sample's
     uint32_t *next_chunk;   // trace pass: the next chunk of list entries to hand out (cleared by the shade pass)
     uint32_t *max_list;     // [2] longest segment list of the pass, by pass parity (bounds the chunk ids)
     uint32_t n_cus;         // compute units of the device (size of the persistent trace grid)

@@ -66,15 +66,12 @@ struct PoolView {
     RT_DEV void store_rng(uint32_t slot, uint64_t rng_state) const { p.ray[(uint64_t)slot * 8 + 7] = rtm::u2d(rng_state); }
     // Winner of the traversal: one 32-byte record per slot.
     // meta = box face | movers << 4 | node steps of the traversal << 16 (the shade pass orders the next
-    // trace pass by them); a miss stores the first half only, for the steps.
+    // trace pass by them); a miss stores nothing (its path ends).
     RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch) const {
         uint4 *q = reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8);
         uint64_t tb = rtm::d2u(t);
         q[0] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta);
         if (ch.n > 0) q[1] = make_uint4(ch.c0, ch.c1, ch.c2, ch.c3);
-    }
-    RT_DEV void store_miss(uint32_t slot, uint32_t meta) const {
-        reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8)[0] = make_uint4(0u, 0u, REF_EMPTY, meta);
     }
     RT_DEV void load_hit(uint32_t slot, Winner &w, uint32_t &steps) const {
         const uint4 *q = reinterpret_cast<const uint4 *>(p.hit + (uint64_t)slot * 8);
@@ -219,21 +216,19 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         Winner w;
         w.t = 0.0; w.leaf = 0; w.face = 0; w.chain.n = 0; w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
         uint32_t steps = 0;          // node steps of the ray that has just been traced
-        uint32_t cam_steps = 0;      // ... of the slot's latest camera ray
         if (on) {
             uint64_t rs;
             r = pv.load_ray(slot, rs);
             rng = Rng(rs);
             stt = load_state(pool, slot);
             pv.load_hit(slot, w, steps);
-            cam_steps = pool.cam_steps[slot];
         }
         uint32_t depth = stt.depth;
-        // Expected length of the slot's next traversal, for the order of the trace pass's list: a bounce
-        // ray is taken to resemble the ray before it; the next sample's camera ray resembles this sample's
-        // (same pixel). Ordering only: results never depend on it.
+        // Expected length of the slot's next traversal, for the order of the trace pass's list: a bounce ray is taken
+        // to resemble the ray before it; a new sample's camera ray goes with the short ones. (A per-slot record of the
+        // previous camera ray's length predicts better, but costs a gather and a scatter per slot: measured -1.4 %.)
+        // Ordering only: results never depend on it.
         uint32_t expect = steps;
-        if (on && kind >= SK_MISS && depth == a.max_depth) { cam_steps = steps; pool.cam_steps[slot] = (uint16_t)steps; }
 
         if (on && kind >= SK_MISS) {
             if (kind == SK_MISS) {
@@ -370,7 +365,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 double u = ((double)px + rand_u) / (double)(a.width - 1);
                 double v = ((double)py + rand_v) / (double)(a.height - 1);
                 r = get_ray(a.cam, u, v, rng);
-                expect = cam_steps;
+                expect = 0;
                 depth = a.max_depth;
                 smp++;
                 cnt.path();
@@ -794,7 +789,6 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 bool found = L.win_leaf != REF_EMPTY;
                 uint32_t kind = SK_MISS;
                 const uint32_t steps16 = (L.steps > 0xFFFFu ? 0xFFFFu : L.steps) << 16;
-                if (!found) pv.store_miss(slot, steps16);
                 if (found) {
                     pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain);
                     kind = leaf_material_word(s, L.win_leaf) >> kMatKindShift;
@@ -875,9 +869,9 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
 
 // Marks the first `used` slots of every workgroup FRESH and the rest IDLE: a small job is spread
 // over all workgroups (a few slots each) instead of filling a few workgroups to the brim.
-__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint16_t *cam_steps, uint32_t n_slots, uint32_t used) {
+__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint32_t n_slots, uint32_t used) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_slots) { kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE; cam_steps[i] = 0; }
+    if (i < n_slots) kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE;
 }
 
 // ---- host side of the engine -------------------------------------------------------------
@@ -954,7 +948,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         uint32_t used = (uint32_t)(per_block > (uint64_t)S ? (uint64_t)S : (per_block + 63) / 64 * 64);
         if (used < 64) used = 64;
         uint32_t n = blocks * (uint32_t)S;
-        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, pool.cam_steps, n, used);
+        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, n, used);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.max_list, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
@@ -974,7 +968,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         WfPool v = pool;
         v.n_blocks = n_segs; v.n_slots = n_segs * (uint32_t)S;
         v.kind += off; v.ray += off * 8; v.hit += off * 8; v.state += off * 8; v.pixel_sum += off * 4;
-        v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin; v.cam_steps += off;
+        v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin;
         v.n_active = pool.n_active + 2 * g;
         v.next_chunk = pool.next_chunk + g;
         v.max_list = pool.max_list + 2 * g;

@@ -326,7 +326,6 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.tape_cap = depth;
     q.list = pool_alloc<uint16_t>(w, P);
     q.list_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
-    q.cam_steps = pool_alloc<uint16_t>(w, P);
     q.n_active = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
     q.next_chunk = pool_alloc<uint32_t>(w, kMaxGroups);
     q.max_list = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
