@@ -217,11 +217,13 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         w.t = 0.0; w.leaf = 0; w.face = 0; w.chain.n = 0; w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
         uint32_t steps = 0;          // node steps of the ray that has just been traced
         if (on) {
-            uint64_t rs;
-            r = pv.load_ray(slot, rs);
-            rng = Rng(rs);
             stt = load_state(pool, slot);
-            pv.load_hit(slot, w, steps);
+            if (kind > SK_MISS) {                                 // (a miss ends its path and a fresh slot has none: neither needs the ray or the winner)
+                uint64_t rs;
+                r = pv.load_ray(slot, rs);
+                rng = Rng(rs);
+                pv.load_hit(slot, w, steps);
+            }
         }
         uint32_t depth = stt.depth;
         // Expected length of the slot's next traversal, for the order of the trace pass's list: a bounce ray is taken
