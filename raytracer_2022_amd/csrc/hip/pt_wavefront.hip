@@ -127,9 +127,10 @@ RT_DEV SlotState load_state(const WfPool &p, uint32_t slot) {
     st.smp = a.z; st.smp_end = a.w; st.depth = b.x; st.px = b.y; st.py = b.z; st.frame = b.w;
     return st;
 }
-RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st) {
+// (A bounce changes the depth only: the first half is rewritten when a new sample or item starts.)
+RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st, bool whole) {
     uint4 *q = reinterpret_cast<uint4 *>(p.state + (uint64_t)slot * 8);
-    q[0] = make_uint4((uint32_t)st.item, (uint32_t)(st.item >> 32), st.smp, st.smp_end);
+    if (whole) q[0] = make_uint4((uint32_t)st.item, (uint32_t)(st.item >> 32), st.smp, st.smp_end);
     q[1] = make_uint4(st.depth, st.px, st.py, st.frame);
 }
 
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
                 pv.store_ray(slot, r, rng.s);
                 stt.depth = depth;
-                store_state(pool, slot, stt);
+                store_state(pool, slot, stt, want_path);
                 uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
                 new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
                 new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
