@@ -198,6 +198,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __syncthreads();
     const uint32_t total = n_sorted;
     const Vec3 background = ld3(a.background);
+    // One sample per work item (spp_chunk = 1): the item's running sum needs no place of its own in the pool.
+    const bool single = a.chunk == 1 && a.spp > 0 && a.max_depth > 0;
     const uint32_t step_shift = (a.node_quorum >> 20) & 0xFu;         // list class = expected steps >> shift (0 = slot order)
 
     for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
@@ -308,10 +310,17 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             if (ended) {
                 uint32_t nb = a.max_depth - depth;
                 Vec3 Lp = tape.unwind(nb, Lterm);
-                double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
-                double2 s0 = ps[0], s1 = ps[1];
-                ps[0] = make_double2(s0.x + Lp.x, s0.y + Lp.y);           // pixel_color += ..., main.rs:150
-                ps[1] = make_double2(s1.x + Lp.z, 0.0);
+                if (single) {                                         // the item's one sample: 0 + L goes straight to its place
+                    uint64_t pix_slot = stt.item / a.n_chunks;
+                    uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
+                    double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
+                    o[0] = 0.0 + Lp.x; o[1] = 0.0 + Lp.y; o[2] = 0.0 + Lp.z;   // pixel_color = 0; pixel_color += ..., main.rs:143,150
+                } else {
+                    double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
+                    double2 s0 = ps[0], s1 = ps[1];
+                    ps[0] = make_double2(s0.x + Lp.x, s0.y + Lp.y);       // pixel_color += ..., main.rs:150
+                    ps[1] = make_double2(s1.x + Lp.z, 0.0);
+                }
             }
             cnt.draws(rng.draws);                                     // words drawn while scattering
             rng.draws = 0;
@@ -325,11 +334,13 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             for (int guard = 0; guard < 1 << 20; guard++) {           // loops only through degenerate items (spp or depth 0)
                 bool need = !have_item || smp == smp_end;
                 if (need && have_item) {                              // section_pixel_color.push(pixel_color), main.rs:152
-                    uint64_t pix_slot = stt.item / a.n_chunks;
-                    uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
-                    double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
-                    const double *ps = pool.pixel_sum + (uint64_t)slot * 4;
-                    o[0] = ps[0]; o[1] = ps[1]; o[2] = ps[2];
+                    if (!single) {
+                        uint64_t pix_slot = stt.item / a.n_chunks;
+                        uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
+                        double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
+                        const double *ps = pool.pixel_sum + (uint64_t)slot * 4;
+                        o[0] = ps[0]; o[1] = ps[1]; o[2] = ps[2];
+                    }
                     have_item = false;
                 }
                 unsigned long long m = __ballot(need);
@@ -351,9 +362,11 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                             smp = chunk_id * a.chunk;
                             smp_end = smp + a.chunk < a.spp ? smp + a.chunk : a.spp;
                             stt.item = item; stt.px = px; stt.py = py; stt.frame = frame;
-                            double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
-                            ps[0] = make_double2(0.0, 0.0);
-                            ps[1] = make_double2(0.0, 0.0);
+                            if (!single) {
+                                double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
+                                ps[0] = make_double2(0.0, 0.0);
+                                ps[1] = make_double2(0.0, 0.0);
+                            }
                             have_item = true;
                         }
                     }
