@@ -114,7 +114,7 @@ struct SlotTape {
     }
 };
 
-// Path bookkeeping of one slot, one 32-byte record: {item (u64), smp, smp_end, depth, px, py, frame}.
+// Path bookkeeping of one slot, one 32-byte record: {item's index in the partial sums (u64), smp, smp_end, depth, px, py, frame}.
 struct SlotState {
     uint64_t item;
     uint32_t smp, smp_end, depth, px, py, frame;
@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     const Vec3 background = ld3(a.background);
     // One sample per work item (spp_chunk = 1): the item's running sum needs no place of its own in the pool.
     const bool single = a.chunk == 1 && a.spp > 0 && a.max_depth > 0;
+    const bool small_job = a.n_items <= 0xFFFFFFFFull;
     const uint32_t step_shift = (a.node_quorum >> 20) & 0xFu;         // list class = expected steps >> shift (0 = slot order)
 
     for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
@@ -311,9 +312,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 uint32_t nb = a.max_depth - depth;
                 Vec3 Lp = tape.unwind(nb, Lterm);
                 if (single) {                                         // the item's one sample: 0 + L goes straight to its place
-                    uint64_t pix_slot = stt.item / a.n_chunks;
-                    uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
-                    double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
+                    double *o = a.partial + stt.item * 3;
                     o[0] = 0.0 + Lp.x; o[1] = 0.0 + Lp.y; o[2] = 0.0 + Lp.z;   // pixel_color = 0; pixel_color += ..., main.rs:143,150
                 } else {
                     double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
@@ -335,9 +334,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 bool need = !have_item || smp == smp_end;
                 if (need && have_item) {                              // section_pixel_color.push(pixel_color), main.rs:152
                     if (!single) {
-                        uint64_t pix_slot = stt.item / a.n_chunks;
-                        uint32_t chunk_id = (uint32_t)(stt.item - pix_slot * a.n_chunks);
-                        double *o = a.partial + ((uint64_t)chunk_id * a.n_pixels + pix_slot) * 3;
+                        double *o = a.partial + stt.item * 3;
                         const double *ps = pool.pixel_sum + (uint64_t)slot * 4;
                         o[0] = ps[0]; o[1] = ps[1]; o[2] = ps[2];
                     }
@@ -352,16 +349,26 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     if (need) {
                         unsigned long long item = wbase + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
                         if (item < a.n_items) {
-                            uint64_t pix_slot = item / a.n_chunks;
-                            uint32_t chunk_id = (uint32_t)(item - pix_slot * a.n_chunks);
-                            uint64_t yi = pix_slot / a.width;
-                            uint32_t px = (uint32_t)(pix_slot - yi * a.width);
+                            uint64_t pix_slot, yi;
+                            uint32_t chunk_id, px;
+                            if (small_job) {                            // (32-bit divisions where everything fits: the usual case)
+                                const uint32_t ps32 = (uint32_t)item / a.n_chunks, y32 = ps32 / a.width;
+                                chunk_id = (uint32_t)item - ps32 * a.n_chunks;
+                                px = ps32 - y32 * a.width;
+                                pix_slot = ps32; yi = y32;
+                            } else {
+                                pix_slot = item / a.n_chunks;
+                                chunk_id = (uint32_t)(item - pix_slot * a.n_chunks);
+                                yi = pix_slot / a.width;
+                                px = (uint32_t)(pix_slot - yi * a.width);
+                            }
                             uint32_t g = a.row_ids[yi];
                             uint32_t frame = g / a.height;
                             uint32_t py = g - frame * a.height;
                             smp = chunk_id * a.chunk;
                             smp_end = smp + a.chunk < a.spp ? smp + a.chunk : a.spp;
-                            stt.item = item; stt.px = px; stt.py = py; stt.frame = frame;
+                            stt.item = (uint64_t)chunk_id * a.n_pixels + pix_slot;     // (kept as the item's place in the partial sums)
+                            stt.px = px; stt.py = py; stt.frame = frame;
                             if (!single) {
                                 double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
                                 ps[0] = make_double2(0.0, 0.0);
