@@ -136,6 +136,8 @@ RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st, boo
 
 // The device copies of the primitive pools carry, above the material index, the slot kind a hit on the primitive
 // leads to (kMatKindShift; rt_scene_create): publishing a winner then costs one dependent load, not three.
+RT_DEV bool t_finite_s(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
+
 RT_DEV uint32_t leaf_material_word(const SceneDev &s, uint32_t leaf) {
     uint32_t idx = RT_REF_INDEX(leaf);
     switch (RT_REF_KIND(leaf)) {
@@ -229,7 +231,9 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 pv.load_hit(slot, w, steps);
             }
         }
-        uint32_t depth = stt.depth;
+        // (top bit of the stored depth: some record of the path's tape is not "finite weight, pdf neither 0 nor NaN")
+        uint32_t depth = stt.depth & 0x7FFFFFFFu;
+        uint32_t tainted = stt.depth >> 31;
         // Expected length of the slot's next traversal, for the order of the trace pass's list: a bounce ray is taken
         // to resemble the ray before it; a new sample's camera ray goes with the short ones. (A per-slot record of the
         // previous camera ray's length predicts better, but costs a gather and a scatter per slot: measured -1.4 %.)
@@ -302,6 +306,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     }
                     uint32_t nb = a.max_depth - depth;
                     tape.put(nb, wgt, p);
+                    tainted |= (t_finite_s(wgt.x) && t_finite_s(wgt.y) && t_finite_s(wgt.z) && p == p && p != 0.0) ? 0u : 1u;
                     r = Ray(rec.p, dir, tm);
                     depth--;
                     if (depth == 0) ended = true;                     // the next ray_color returns (0,0,0), main.rs:240-242
@@ -310,7 +315,11 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             }
             if (ended) {
                 uint32_t nb = a.max_depth - depth;
-                Vec3 Lp = tape.unwind(nb, Lterm);
+                // Unwinding from an exact zero through records with finite weights and usable pdfs gives 0 + (w * 0) / p =
+                // +0 at every step (a black background, a light seen from behind, an exhausted depth): the tape need not
+                // be read. Anything else — a pdf of 0, an infinite weight: the reference's NaN pixels — is unwound.
+                Vec3 Lp(0.0, 0.0, 0.0);
+                if (!(nb >= 1 && !tainted && Lterm.x == 0.0 && Lterm.y == 0.0 && Lterm.z == 0.0)) Lp = tape.unwind(nb, Lterm);
                 if (single) {                                         // the item's one sample: 0 + L goes straight to its place
                     double *o = a.partial + stt.item * 3;
                     o[0] = 0.0 + Lp.x; o[1] = 0.0 + Lp.y; o[2] = 0.0 + Lp.z;   // pixel_color = 0; pixel_color += ..., main.rs:143,150
@@ -390,6 +399,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 r = get_ray(a.cam, u, v, rng);
                 expect = 0;
                 depth = a.max_depth;
+                tainted = 0;
                 smp++;
                 cnt.path();
                 cnt.draws(rng.draws);                                 // words drawn while aiming the camera ray
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             if (alive) {
                 cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
                 pv.store_ray(slot, r, rng.s);
-                stt.depth = depth;
+                stt.depth = depth | (tainted << 31);
                 store_state(pool, slot, stt, want_path);
                 uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
                 new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
