@@ -3,19 +3,33 @@
 
 One step = one pass of the hot path over one frame's worth of rows per GPU:
 the book-2 final scene at 800x800x1000 spp (BASELINE.json's metric config) with the
-scene, camera and row list already resident in HBM. At N GPUs the job is an
+scene, camera and row list already resident in HBM. At N GPUs the default job is an
 N-frame film strip whose rows are dealt cyclically to the ranks (weak scaling,
-raytracer_2022_amd/film.py); the only exchange is the gather of the row buffers.
+raytracer_2022_amd/film.py); `--scaling strong` splits ONE frame's rows over the
+ranks instead (BASELINE configs 4 and 5). The only exchange is the gather of the
+row buffers.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      algorithmic bytes / kernel time vs 8 TB/s HBM
-  cpu_baseline  the CPU oracle on a bounded sample of the same workload
+  roofline      the dominant kernel (wf_trace) against the HBM roofline of SURVEY.md §8(d)
+                (algorithmic bytes per launch / mean launch duration from HIP events),
+                next to what the counters say really limits it: L2 bandwidth, VALU issue,
+                measured HBM traffic — every figure recomputable from the fields beside it
+  cpu_baseline  the CPU oracle on a bounded sample of the same workload, at the
+                reference's 8 threads (main.rs:40) and at all usable cores
+The PMC figures come from rocprofv3 passes this script runs on itself before it
+touches the GPU (N=1 only; `--no-pmc` skips them, and the traffic then falls back to
+the committed profile of the same workload, marked as such).
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,17 +51,35 @@ SCENE_PARAM = {"c5": 3}
 BYTES_NODE = 64
 BYTES_PRIM = {"sphere": 40, "moving_sphere": 80, "rect": 48, "box": 56, "triangle": 80, "ring": 32,
               "medium": 24, "translate": 56, "rotate_y": 56, "zoom": 56, "list": 8, "node": 0}
-BYTES_RAY_STATE = 256      # 128 B read + 128 B write per ray segment
+BYTES_RAY_READ = 128       # per ray segment: 128 B of state read ...
+BYTES_RAY_WRITE = 128      # ... and 128 B written
 BYTES_PIXEL = 24
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+# Peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # HBM3E, spec (6 290 measured by a float4 copy)
+L2_PEAK_GBS = 34500.0      # aggregate of the eight 4 MiB L2s
+FP64_VECTOR_TFLOPS = 78.6  # = 39.3 T f64 lane-instructions/s (an FMA counts two flops)
+N_SIMDS = 256 * 4
+L2_BYTES = 32 << 20
 
 
 def algorithmic_bytes(st, n_pixels):
+    """bytes = 64 N_node + sum_type size N_type + 256 N_ray + 24 N_pixel, split by the kernel that
+    moves them: the traversal kernel fetches nodes and primitives, reads each ray and writes its winner (half of the
+    per-ray state traffic); the shading kernel has the other half and the pixels."""
     from raytracer_2022_amd import _ffi as F
     prim = sum(BYTES_PRIM[F.KIND_NAMES[k]] * st["prim_tests"][k] for k in range(F.RT_KIND_COUNT))
     traversal = BYTES_NODE * st["node_visits"] + prim
-    return {"traversal": traversal, "ray_state": BYTES_RAY_STATE * st["rays"], "pixels": BYTES_PIXEL * n_pixels,
-            "total": traversal + BYTES_RAY_STATE * st["rays"] + BYTES_PIXEL * n_pixels}
+    trace = traversal + BYTES_RAY_READ * st["rays"]
+    shade = BYTES_RAY_WRITE * st["rays"] + BYTES_PIXEL * n_pixels
+    return {"traversal": traversal, "wf_trace": trace, "wf_shade": shade, "total": trace + shade}
+
+
+def scene_bytes(desc):
+    from raytracer_2022_amd import _ffi as F
+    d = desc
+    return (d.n_nodes * C.sizeof(F.rt_bvh_node) + d.n_spheres * C.sizeof(F.rt_sphere) + d.n_moving_spheres * C.sizeof(F.rt_moving_sphere)
+            + d.n_rects * C.sizeof(F.rt_rect) + d.n_boxes * C.sizeof(F.rt_box) + d.n_triangles * C.sizeof(F.rt_triangle)
+            + d.n_rings * C.sizeof(F.rt_ring) + d.n_media * C.sizeof(F.rt_medium) + d.n_xforms * C.sizeof(F.rt_xform))
 
 
 def usable_cores():
@@ -63,20 +95,117 @@ def usable_cores():
     return max(1, n)
 
 
-def measured_traffic(config, spp, spp_chunk):
-    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/r1_hbm_traffic.json), when they
-    were taken on exactly this workload; otherwise None. bench.py cannot run the profiler on itself."""
+def cpu_model():
     try:
-        for t in json.load(open(os.path.join(HERE, "profiles", "r1_hbm_traffic.json")))["runs"]:
-            if t.get("config") == config and t.get("spp") == spp and t.get("spp_chunk") == spp_chunk:
-                return int(t["total_bytes"])
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
         pass
-    return None
+    return "unknown"
+
+
+def committed_traffic(config, spp, spp_chunk):
+    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/*hbm_traffic.json), when they were
+    taken on exactly this workload; otherwise None. The fallback when the in-run PMC passes are off or fail."""
+    best = None
+    for name in sorted(glob.glob(os.path.join(HERE, "profiles", "*hbm_traffic.json"))):
+        try:
+            for t in json.load(open(name))["runs"]:
+                if t.get("config") == config and t.get("spp") == spp and t.get("spp_chunk") == spp_chunk:
+                    best = (t, os.path.relpath(name, HERE))
+        except Exception:
+            pass
+    return best
+
+
+# ---------------------------------------------------------------------------------------------
+# In-run PMC passes: this script under rocprofv3, in `--inner-frame` mode (one frame through the
+# library's host-buffer entry point, no torch), once per counter set — FETCH_SIZE and WRITE_SIZE
+# cannot share a pass (TCC slots), and the counter passes never carry a trace (MI355X_MICROARCH.md).
+# ---------------------------------------------------------------------------------------------
+PMC_PASSES = [
+    ["FETCH_SIZE", "GRBM_GUI_ACTIVE"],
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_WAVES"],
+]
+
+
+def run_pmc(args, spp, spp_chunk, budget_s):
+    """{kernel: {counter: total over one frame}} or (None, reason). Runs before the parent touches the GPU."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    t_all = time.time()
+    tmp = tempfile.mkdtemp(prefix="rt2022_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            left = budget_s - (time.time() - t_all)
+            if left < 20:
+                return None, "PMC time budget spent after %d passes" % i
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                                               "--inner-frame", "--config", args.config, "--spp", str(spp), "--spp-chunk", str(spp_chunk),
+                                               "--seed", str(args.seed), "--assets", args.assets]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            p = subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                log, _ = p.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, 9)           # (the group this call started, nothing else)
+                except Exception:
+                    pass
+                p.wait()
+                return None, "PMC pass %d timed out" % i
+            if p.returncode != 0:
+                return None, "PMC pass %d failed: %s" % (i, log.decode(errors="replace")[-300:].replace("\n", " | "))
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "PMC pass %d wrote no counter_collection.csv" % i
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        k = row.get("Kernel_Name", "")
+                        name = "wf_trace" if "wf_trace" in k else "wf_shade" if "wf_shade" in k else "chunk_sum" if "chunk_sum" in k else None
+                        if name is None:
+                            continue
+                        slot = out.setdefault(name, {})
+                        slot[row["Counter_Name"]] = slot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                        if i == 0 and row["Counter_Name"] == counters[0]:
+                            slot["_dispatches"] = slot.get("_dispatches", 0) + 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, "rocprofv3 --pmc, %d passes of one frame each, %.0f s" % (len(PMC_PASSES), time.time() - t_all)
+
+
+def hbm_bytes(c):
+    """MI355X_MICROARCH.md §HBM: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts 64 B
+    per 128-B request, so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores."""
+    rd = c.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
+    wr = c.get("WRITE_SIZE", 0.0) * 1024.0
+    return rd, wr
+
+
+def inner_frame(args):
+    """One frame of the workload through rt_render (host buffers): the dispatches the profiler counts."""
+    import raytracer_2022_amd as rt
+    scene_name, W, H, spp, _ = CONFIGS[args.config]
+    spp = args.spp or spp
+    assets = args.assets if os.path.isdir(args.assets) else None
+    scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
+    cam, bg = scene.default_view(W / H)
+    params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, spp_chunk=args.spp_chunk)
+    rows = rt.shuffled_rows(H, args.seed)
+    dev = rt.DeviceScene(scene.desc)
+    out = dev.render(cam, params, rows)
+    assert np.isfinite(out).any()
 
 
 def cpu_baseline(scene, cam, params, height, seed, target_s):
-    """Time the oracle (the reference's threading scheme) on a bounded sample of the same workload."""
+    """Time the oracle (the reference's threading scheme, main.rs:93-116) on a bounded sample of the same workload:
+    at all usable cores, and at the reference's THREAD_NUMBER = 8 (main.rs:40)."""
     from oracle import oracle_ffi as O
     from raytracer_2022_amd import _ffi as F, shuffled_rows
     cores = usable_cores()
@@ -88,20 +217,31 @@ def cpu_baseline(scene, cam, params, height, seed, target_s):
     _, st = O.render_cpu(scene.desc, cam, p, sub, n_threads=cores, want_stats=True)
     dt = max(time.time() - t0, 1e-3)
     rate = st.rays / dt
-    # scale the sample (rows x spp) to ~target_s seconds of CPU work
-    want_rays = rate * target_s
     rays_per_row_spp = st.rays / len(sub)
-    spp = int(max(1, min(params.spp, want_rays / (rays_per_row_spp * height))))
-    n_rows = int(max(cores, min(height, want_rays / (rays_per_row_spp * spp))))
-    p.spp = spp
-    sample_rows = rows[:n_rows]
-    t0 = time.time()
-    _, st = O.render_cpu(scene.desc, cam, p, sample_rows, n_threads=cores, want_stats=True)
-    dt = time.time() - t0
-    return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d shuffled rows x %d px x %d spp of the same scene/camera, %d threads in the reference's "
-                      "contiguous-section scheme (main.rs:109-116), %.1f s" % (n_rows, params.width, spp, cores, dt),
-            "rays": int(st.rays), "seconds": round(dt, 2)}
+
+    def sample(n_threads, seconds):
+        want_rays = rate * seconds * n_threads / cores
+        spp = int(max(1, min(params.spp, want_rays / (rays_per_row_spp * height))))
+        n_rows = int(max(n_threads, min(height, want_rays / (rays_per_row_spp * spp))))
+        p.spp = spp
+        t0 = time.time()
+        _, s2 = O.render_cpu(scene.desc, cam, p, rows[:n_rows], n_threads=n_threads, want_stats=True)
+        dt = time.time() - t0
+        return {"value": round(s2.rays / dt / 1e6, 3), "cores": n_threads, "rays": int(s2.rays), "seconds": round(dt, 2),
+                "sample": "%d shuffled rows x %d px x %d spp of the same scene/camera, %d threads in the reference's "
+                          "contiguous-section scheme (main.rs:109-116), %.1f s" % (n_rows, params.width, spp, n_threads, dt)}
+    full = sample(cores, target_s * 0.6)
+    out = {"value": full["value"], "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": full["sample"],
+           "rays": full["rays"], "seconds": full["seconds"], "cpu_model": cpu_model(),
+           "logical_cpus_visible": os.cpu_count(), "cores_note": "cores = affinity mask capped by the cgroup CPU quota"}
+    if cores > 8:
+        t8 = sample(8, target_s * 0.4)
+        out["t8"] = {"value": t8["value"], "unit": "Mrays/s", "cores": 8, "sample": t8["sample"],
+                     "note": "the reference's hard-coded THREAD_NUMBER (main.rs:40)"}
+    else:
+        out["t8"] = {"value": full["value"] if cores == 8 else None, "unit": "Mrays/s", "cores": 8,
+                     "note": "only %d cores usable here" % cores}
+    return out
 
 
 def main():
@@ -110,21 +250,25 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one frame per GPU (an N-frame strip); strong: ONE frame, its rows dealt over the GPUs")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (a reduced-spp run is NOT the headline number)")
     ap.add_argument("--spp-chunk", type=int, default=-1,
                     help="samples per work item; default: 1 (the reference's summation order) unless the per-sample partial sums "
-                         "would exceed 32 GB of HBM, then the smallest chunk that fits")
+                         "would exceed 100 GB of HBM, then the smallest chunk that fits")
     ap.add_argument("--seed", type=int, default=2022)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
+    ap.add_argument("--pmc-seconds", type=float, default=240.0, help="time budget of the counter passes")
     ap.add_argument("--assets", default=os.path.join(HERE, "assets"))
+    ap.add_argument("--inner-frame", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import raytracer_2022_amd as rt
-    from raytracer_2022_amd import _ffi as F, film
+    if args.inner_frame:
+        inner_frame(args)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +278,26 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
                   % (args.gpus, world, args.gpus), file=sys.stderr)
         sys.exit(2)
+
+    scene_name, W, H, spp, desc_text = CONFIGS[args.config]
+    if args.spp > 0:
+        spp = args.spp
+    n_frames = world if args.scaling == "weak" else 1
+    rows_per_gpu = H * n_frames // world
+    if args.spp_chunk < 0:
+        per_sample = rows_per_gpu * W * 24.0                # bytes of partial sums per sample index on one GPU
+        args.spp_chunk = max(1, int(-(-spp * per_sample // 100e9)))
+
+    # Counter passes first: child processes, started before this process has touched the GPU.
+    pmc, pmc_note = (None, "N > 1" if world > 1 else "--no-pmc")
+    if world == 1 and not args.no_pmc:
+        pmc, pmc_note = run_pmc(args, spp, args.spp_chunk, args.pmc_seconds)
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_2022_amd as rt
+    from raytracer_2022_amd import _ffi as F, film
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -143,23 +307,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    scene_name, W, H, spp, desc_text = CONFIGS[args.config]
-    if args.spp > 0:
-        spp = args.spp
     assets = args.assets if os.path.isdir(args.assets) else None
     scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
     cam, bg = scene.default_view(W / H)
-    if args.spp_chunk < 0:
-        per_sample = H * W * 24.0                           # bytes of partial sums per sample index (H rows per GPU)
-        args.spp_chunk = max(1, int(-(-spp * per_sample // 32e9)))
-    params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=world, spp_chunk=args.spp_chunk)
+    params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=n_frames, spp_chunk=args.spp_chunk)
+    params.flags |= F.RT_FLAG_KERNEL_TIMES
     dscene = rt.DeviceScene(scene.desc)
 
-    rows = film.rank_rows(H, world, args.seed, rank, world)
+    rows = film.rank_rows(H, n_frames, args.seed, rank, world)
     n_rows = len(rows)
     d_rows = torch.from_numpy(rows.view(np.int32)).to(dev)
     d_out = torch.empty((n_rows, W, 3), dtype=torch.float64, device=dev)
-    gather_list = [torch.empty_like(d_out) for _ in range(world)] if (world > 1 and rank == 0 and not args.no_gather) else None
+    # (strong scaling deals H rows over `world` ranks: the shares differ by at most one row; gather needs equal shapes)
+    max_rows = -(-H * n_frames // world)
+    d_pad = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev) if max_rows != n_rows else None
+    gather_list = [torch.empty((max_rows, W, 3), dtype=torch.float64, device=dev) for _ in range(world)] \
+        if (world > 1 and rank == 0 and not args.no_gather) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -170,11 +333,15 @@ def main():
     def step(stats=None):
         dscene.render_device(cam, params, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, stats)
         if world > 1 and not args.no_gather:
-            dist.gather(d_out, gather_list, dst=0)
+            src = d_out
+            if d_pad is not None:
+                d_pad[:n_rows].copy_(d_out)
+                src = d_pad
+            dist.gather(src, gather_list, dst=0)
 
     # Counter pass (untimed, deterministic): rays / node visits / primitive tests of one step.
     pc = F.rt_params.from_buffer_copy(params)
-    pc.flags |= F.RT_FLAG_COUNTERS
+    pc.flags = F.RT_FLAG_COUNTERS
     st = F.rt_stats()
     dscene.render_device(cam, pc, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, st)
     dscene.wait(stream)
@@ -183,13 +350,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
+    kernel_ms, trace_ms, shade_ms, passes = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s = F.rt_stats()
         step(s)
-        dscene.wait(stream)          # fills s.ms from the HIP events bracketing the launches on `stream`
-        kernel_ms.append(s.ms)
+        dscene.wait(stream)          # fills s.ms / s.trace_ms / s.shade_ms from the HIP events on `stream`
+        kernel_ms.append(s.ms); trace_ms.append(s.trace_ms); shade_ms.append(s.shade_ms); passes.append(s.passes)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -205,33 +372,106 @@ def main():
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
         value = total_rays * args.steps / elapsed / 1e6 if args.steps else 0.0
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        tr_ms = float(np.mean(trace_ms)) if trace_ms else float("nan")
+        sh_ms = float(np.mean(shade_ms)) if shade_ms else float("nan")
+        n_pass = int(round(float(np.mean(passes)))) if passes else 0
         ab = algorithmic_bytes(counts, n_rows * W)
-        achieved = ab["total"] / (k_ms * 1e-3) / 1e9
+        gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
+        rnd = lambda x, n=2: None if x is None else round(x, n)
+        frac = lambda x, peak: None if x is None else round(x / peak, 4)
+        achieved = gbs(ab["wf_trace"], tr_ms)
+        sbytes = scene_bytes(scene.desc)
+
+        roof = {
+            "bound": "hbm", "kernel": "wf_trace (BVH traversal + Hittable::hit, pt_wavefront.hip): %.0f %% of the frame's device time" % (100.0 * tr_ms / k_ms if k_ms else 0),
+            "achieved": rnd(achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(achieved, HBM_PEAK_GBS),
+            "traffic": None, "traffic_unit": "HBM bytes per wf_trace launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes)",
+            "launches_per_step": n_pass, "launch_ms": rnd(tr_ms / n_pass if n_pass else None, 4),
+            "algorithmic_bytes_per_launch": int(ab["wf_trace"] / n_pass) if n_pass else None,
+            "algorithmic_bytes_per_step": {k: int(v) for k, v in ab.items()},
+            "device_ms_per_step": {"all": rnd(k_ms, 3), "wf_trace": rnd(tr_ms, 3), "wf_shade": rnd(sh_ms, 3)},
+            "whole_frame": {"achieved": rnd(gbs(ab["total"], k_ms)), "frac": frac(gbs(ab["total"], k_ms), HBM_PEAK_GBS)},
+            "traversal_only": {"bytes": int(ab["traversal"]), "achieved": rnd(gbs(ab["traversal"], tr_ms)),
+                               "frac": frac(gbs(ab["traversal"], tr_ms), HBM_PEAK_GBS)},
+            # the same traversal bytes against the level that really serves them when the scene fits in cache
+            "l2": {"achieved": rnd(gbs(ab["traversal"], tr_ms)), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                   "frac": frac(gbs(ab["traversal"], tr_ms), L2_PEAK_GBS),
+                   "scene_bytes": int(sbytes), "fits_aggregate_l2": bool(sbytes <= L2_BYTES)},
+            "pmc": pmc_note,
+        }
+        limiter = []
+        if pmc and "wf_trace" in pmc:
+            c = pmc["wf_trace"]
+            rd, wr = hbm_bytes(c)
+            launches = max(1, int(c.get("_dispatches", n_pass or 1)))
+            if rd + wr > 0:
+                roof["traffic"] = int((rd + wr) / launches)
+                roof["traffic_per_step"] = {"wf_trace": int(rd + wr), "read": int(rd), "write": int(wr)}
+                if "wf_shade" in pmc:
+                    r2, w2 = hbm_bytes(pmc["wf_shade"])
+                    roof["traffic_per_step"]["wf_shade"] = int(r2 + w2)
+                hb = gbs(rd + wr, tr_ms)
+                roof["hbm_counter"] = {"achieved": rnd(hb), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(hb, HBM_PEAK_GBS),
+                                       "bytes_per_ray": rnd((rd + wr) / max(counts["rays"], 1), 1),
+                                       "over_algorithmic_ray_state": rnd((rd + wr) / max(BYTES_RAY_READ * counts["rays"], 1), 2)}
+                limiter.append(("hbm", roof["hbm_counter"]["frac"]))
+            if c.get("SQ_INSTS_VALU"):
+                util = c.get("SQ_THREAD_CYCLES_VALU", 0.0) / (c.get("SQ_ACTIVE_INST_VALU", 0.0) * 64.0) if c.get("SQ_ACTIVE_INST_VALU") else None
+                lane_ops = c["SQ_INSTS_VALU"] * 64.0 * (util or 0.0)
+                t_s = tr_ms * 1e-3
+                # issue-side view: an f64 wave-instruction holds its SIMD for 4 cycles (16 f64 lanes per clock);
+                # clock from GRBM_GUI_ACTIVE (summed over the 8 XCDs) over the profiled kernel time when available
+                roof["valu"] = {
+                    "wave_instructions_per_step": int(c["SQ_INSTS_VALU"]), "lane_utilisation": rnd(util, 4),
+                    "achieved": rnd(lane_ops / t_s / 1e12, 3), "peak": FP64_VECTOR_TFLOPS / 2.0, "unit": "T f64 lane-instructions/s",
+                    "frac": frac(lane_ops / t_s / 1e12, FP64_VECTOR_TFLOPS / 2.0),
+                    "issue_busy": rnd(c["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * 2.4e9 * t_s), 4),
+                    "issue_busy_note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x wf_trace time): share of the chip's VALU issue slots the kernel's wave-instructions occupy, idle lanes included",
+                    "wait_any_over_wave_cycles": rnd(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if c.get("SQ_WAVE_CYCLES") else None,
+                    "salu_per_valu": rnd(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3),
+                }
+                limiter.append(("valu_issue", roof["valu"]["issue_busy"]))
+        elif world == 1:
+            tc = committed_traffic(args.config, spp, args.spp_chunk)
+            if tc:
+                t_, src = tc
+                tb = t_.get("by_kernel", {}).get("wf_trace")
+                if tb and n_pass:
+                    roof["traffic"] = int((tb["read"] + tb["write"]) / n_pass)
+                    roof["traffic_source"] = "committed profile %s (not measured by this run: %s)" % (src, pmc_note)
+        if roof["l2"]["frac"] is not None and roof["l2"]["fits_aggregate_l2"]:
+            limiter.append(("l2", roof["l2"]["frac"]))
+        if limiter:
+            limiter.sort(key=lambda kv: -(kv[1] or 0))
+            roof["limiter"] = {"resource": limiter[0][0], "frac": limiter[0][1], "ranked": limiter,
+                               "note": "bound = the contractual roofline of SURVEY.md §8(d); limiter = the resource the counters of this run show closest to its ceiling"}
+        note = ["scene %.2f MB (%s the 32 MiB of aggregate L2)" % (sbytes / 1e6, "fits" if sbytes <= L2_BYTES else "exceeds")]
+        if roof.get("hbm_counter"):
+            note.append("measured HBM traffic of wf_trace %.0f B per ray segment = %.2f of the 8 TB/s peak, against an algorithmic fraction of %.2f: "
+                        "the node and primitive bytes are served by the caches" % (roof["hbm_counter"]["bytes_per_ray"], roof["hbm_counter"]["frac"], roof["frac"] or 0))
+        if roof.get("valu"):
+            note.append("wf_trace issues %.2f of the chip's VALU slots at %.0f %% lane utilisation and its waves wait %.0f %% of their cycles"
+                        % (roof["valu"]["issue_busy"], 100 * (roof["valu"]["lane_utilisation"] or 0), 100 * (roof["valu"]["wait_any_over_wave_cycles"] or 0)))
+        roof["note"] = "; ".join(note)
+
         out = {
             "metric": "Mrays/s (primary+secondary), book-2 final scene 800x800x1000spp" if args.config == "c3" and args.spp == 0
                       else "Mrays/s (primary+secondary)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc_text if args.spp == 0 else desc_text + " [spp overridden to %d]" % spp,
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "max_depth": 50,
-                       "frames": world, "rows_per_gpu": n_rows, "spp_chunk": args.spp_chunk, "seed": args.seed,
-                       "sharding": "rows of an N-frame strip dealt cyclically; gather of row buffers to rank 0",
-                       "earth_texture": "assets/earthmap.ppm" if assets else "procedural stand-in"},
+                       "frames": n_frames, "rows_per_gpu": n_rows, "spp_chunk": int(s.spp_chunk) if kernel_ms else args.spp_chunk,
+                       "pool_slots": int(s.pool_slots) if kernel_ms else None, "seed": args.seed,
+                       "sharding": ("rows of an N-frame strip dealt cyclically (one frame's worth per GPU)" if args.scaling == "weak"
+                                    else "rows of ONE frame dealt cyclically over the GPUs") + "; gather of row buffers to rank 0",
+                       "earth_texture": "assets/earthmap.ppm" if assets and os.path.exists(os.path.join(assets, "earthmap.ppm")) else "procedural stand-in"},
             "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.config, spp, args.spp_chunk) if world == 1 else None,
-                         "traffic_unit": "bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_hbm_traffic.json)",
-                         "kernel": "wf_trace + wf_shade passes of one frame (pt_wavefront.hip)", "kernel_ms": round(k_ms, 3),
-                         "algorithmic_bytes_per_launch": int(ab["total"]),
-                         "traversal_only": {"bytes": int(ab["traversal"]),
-                                            "achieved": round(ab["traversal"] / (k_ms * 1e-3) / 1e9, 2),
-                                            "frac": round(ab["traversal"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                         "note": "170 KB scene is L2-resident, so HBM traffic << algorithmic bytes; the traversal waits on L2 latency (64 % of wave cycles) at 33 % lane utilisation — DESIGN.md §6"},
+            "roofline": roof,
             "counters_rank0": counts,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 p1 = rt.make_params(W, H, spp, 50, bg, seed=args.seed)
                 out["cpu_baseline"] = cpu_baseline(scene, cam, p1, H, args.seed, args.cpu_seconds)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT2022_ABI_VERSION 1
+#define RT2022_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- refs --- */
 /* A hittable reference = one `Arc<dyn Hittable>` of the reference, as a tagged
@@ -263,6 +263,7 @@ typedef struct rt_params {
 } rt_params;
 
 #define RT_FLAG_COUNTERS 0x1u         /* fill the counter fields of rt_stats */
+#define RT_FLAG_KERNEL_TIMES 0x2u     /* fill rt_stats.trace_ms / shade_ms (HIP events around every pass of the default engine) */
 
 typedef struct rt_stats {
     uint64_t paths;                               /* camera rays                         */
@@ -272,6 +273,12 @@ typedef struct rt_stats {
     uint64_t light_pdf_tests;                     /* pdf_value re-intersections          */
     uint64_t rng_draws;                           /* 64-bit words drawn on the path      */
     double   ms;                                  /* device (or CPU) time of the call    */
+    /* How the call was carried out (always filled; speed only, never results): */
+    uint32_t spp_chunk;                           /* samples per work item actually used (params->spp_chunk, 0 resolved to spp) */
+    uint32_t passes;                              /* shade + trace pass pairs of the wavefront engine (0: megakernel, CPU) */
+    uint64_t pool_slots;                          /* path slots of the wavefront pool the call ran with */
+    double   trace_ms, shade_ms;                  /* RT_FLAG_KERNEL_TIMES: device time summed over the call's traversal (wf_trace) and
+                                                     shading (wf_shade) launches; 0 otherwise */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;     /* opaque: device-resident scene */
@@ -300,7 +307,12 @@ int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
  * from the host and polls a completion word, so the call returns when the frame's
  * last pass has been issued and observed (it synchronises `hip_stream`); `stats`,
  * if given, is filled by the next rt_render_wait on the same stream. One host
- * thread per (scene, stream). */
+ * thread per (scene, stream). The device-resident row ids are checked like
+ * rt_render's host ones (one small reduction kernel): an id >= height * n_frames
+ * is RT_ERR_INVALID, not a silently mis-keyed frame.
+ * The scene lives on the HIP device that was current at rt_scene_create; the call
+ * makes that device current for its duration and restores the caller's, and
+ * `hip_stream`, the row ids and the output must belong to that device. */
 int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                      double *d_out_rgb_sum, void *hip_stream, rt_stats *stats);
 int rt_render_wait(rt_scene *scene, void *hip_stream);

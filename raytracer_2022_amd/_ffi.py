@@ -7,7 +7,7 @@ library has not been built — there is no Python or CPU fallback for the path.
 import ctypes as C
 import os
 
-RT2022_ABI_VERSION = 1
+RT2022_ABI_VERSION = 2
 
 RT_REF_FLIP = 0x80000000
 RT_REF_KIND_SHIFT = 27
@@ -21,6 +21,7 @@ RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC, RT_MAT_DIFFUSE_LIGHT, RT_MAT
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE = range(4)
 RT_MAX_XFORM_DEPTH = 4
 RT_FLAG_COUNTERS = 0x1
+RT_FLAG_KERNEL_TIMES = 0x2
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 KIND_NAMES = ["node", "sphere", "moving_sphere", "rect", "box", "triangle", "ring", "medium",
@@ -135,7 +136,9 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("prim_tests", C.c_uint64 * RT_KIND_COUNT), ("light_pdf_tests", C.c_uint64),
-                ("rng_draws", C.c_uint64), ("ms", C.c_double)]
+                ("rng_draws", C.c_uint64), ("ms", C.c_double),
+                ("spp_chunk", C.c_uint32), ("passes", C.c_uint32), ("pool_slots", C.c_uint64),
+                ("trace_ms", C.c_double), ("shade_ms", C.c_double)]
 
     def as_dict(self):
         return {"paths": self.paths, "rays": self.rays, "node_visits": self.node_visits,

@@ -172,14 +172,30 @@ RT_DEV void xform_record(const SceneDev &s, uint32_t ref, const XRay &moved, Hit
 }
 
 // Chain of enclosing movers, outermost first.
+#ifndef RT2022_CHAIN_PACKED
+#define RT2022_CHAIN_PACKED 0
+#endif
 struct Chain {
     uint32_t c0, c1, c2, c3;
     uint32_t n;
+#if RT2022_CHAIN_PACKED
+    // (A/B form for tools/mega_bisect.sh: the four refs picked with shifts of two 64-bit words, which the
+    // compiler cannot turn into an indexed private array.)
+    RT_DEV uint32_t at(uint32_t i) const {
+        const uint64_t lo = (uint64_t)c0 | ((uint64_t)c1 << 32), hi = (uint64_t)c2 | ((uint64_t)c3 << 32);
+        return (uint32_t)(((i & 2u) ? hi : lo) >> ((i & 1u) * 32u));
+    }
+    RT_DEV void push(uint32_t ref) {
+        c0 = n == 0 ? ref : c0; c1 = n == 1 ? ref : c1; c2 = n == 2 ? ref : c2; c3 = n >= 3 ? ref : c3;
+        n++;
+    }
+#else
     RT_DEV uint32_t at(uint32_t i) const { return i == 0 ? c0 : i == 1 ? c1 : i == 2 ? c2 : c3; }
     RT_DEV void push(uint32_t ref) {
         if (n == 0) c0 = ref; else if (n == 1) c1 = ref; else if (n == 2) c2 = ref; else c3 = ref;
         n++;
     }
+#endif
 };
 RT_DEV XRay ray_at_level(const SceneDev &s, const Chain &ch, uint32_t level, XRay world) {
     XRay r = world;

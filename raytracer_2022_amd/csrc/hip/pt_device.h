@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../../include/rt2022.h"
 
 namespace rt2022 {
@@ -116,6 +118,7 @@ struct WfPool {
     uint32_t *max_list;     // [2] longest segment list of the pass, by pass parity (bounds the chunk ids)
     uint32_t n_cus;         // compute units of the device (size of the persistent trace grid)
     uint32_t *n_active;     // [2] rays handed to the next trace pass, by pass parity (polled by the host)
+    uint32_t *fault;        // [1] engine invariants found broken on the device (bit 0: a slot reached the shade pass untraced)
     // Pass-timing probe (rt_debug_pass_timing; null otherwise): {first wave start, last wave end, sum of
     // wave lifetimes, sum of wave time after the list ran dry, waves} in wall_clock64 ticks.
     unsigned long long *dbg;
@@ -147,12 +150,19 @@ struct WfStreams {
     hipEvent_t ev[kMaxGroups][2] = {};
     uint32_t *h_active = nullptr;      // pinned, [kMaxGroups][2]
 };
+// Per-kernel device time of one render (RT_FLAG_KERNEL_TIMES): HIP events on the launch stream around every pass.
+struct KernelTimes {
+    std::vector<hipEvent_t> ev;        // grown on demand, reused from call to call
+    double shade_ms = 0.0, trace_ms = 0.0;
+};
 // Wavefront engine: alternates shade / trace passes over the pool until it drains.
 // Blocks the calling thread (polls `n_active`). d_args is the device-resident copy of `args`.
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                    const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations,
-                                   double *timing /* null, or [5]: see rt_debug_pass_timing */);
+                                   double *timing /* null, or [5]: see rt_debug_pass_timing */,
+                                   uint32_t *out_fault /* WfPool::fault after the last pass */,
+                                   KernelTimes *kt /* null, or where to put the per-kernel times (forces one group) */);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

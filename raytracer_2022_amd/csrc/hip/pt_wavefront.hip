@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         const bool on = j < total;
         uint32_t slot = 0, kind = SK_IDLE;
         if (on) { uint32_t e = sorted[j]; slot = base + (e & 0xFFFFu); kind = e >> 16; }
+        // Every slot that carried a ray has been through the trace pass by now. One that has not would lose its
+        // path without a trace (it is neither shaded nor re-listed): report it instead — the render then fails.
+        if (on && kind == SK_TRACE) atomicOr(pool.fault, 1u);
         bool alive = false;          // path continues with a new ray
         bool ended = false;          // path ended: add to pixel, start the next sample
         Ray r;
@@ -579,9 +582,12 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     const uint32_t n_seg = pool.n_blocks;
     const uint32_t total_ids = ((pool.max_list[parity] + kChunk - 1u) / kChunk) * n_seg;
     // This wave's chunk — entries [base + taken, base + n) of pool.list — and "the counter has run out": per-wave
-    // state, kept in LDS rather than in four more live registers (the kernel has none to spare).
+    // state, kept in LDS rather than in four more live registers (the kernel has none to spare). Written by the
+    // wave's leader lane and read by whichever lanes publish next: volatile, so every access is a real ds_read /
+    // ds_write in program order — one wave's LDS operations complete in the order it issues them, and the compiler
+    // may not carry the words in registers from one round to the next.
     __shared__ uint32_t chunk_lds[kBlock / 64][4];
-    uint32_t *const cs = chunk_lds[tid >> 6];
+    volatile uint32_t *const cs = chunk_lds[tid >> 6];
     if (lane < 4) cs[lane] = 0;
     const bool probe = PROBE && pool.dbg != nullptr;                  // (rt_debug_pass_timing: a build of its own, all arms)
     unsigned long long t_start = 0, t_dry = 0;
@@ -947,9 +953,11 @@ static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity)
         default: launch_trace<STACK, false, 7, PROBE>(w, parity); break;
     }
 }
-static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters, bool probe) {
+static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need, unsigned features, bool counters, bool probe,
+                        hipEvent_t between = nullptr) {
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
+    if (between) (void)hipEventRecord(between, w.stream);
     if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
         else if (probe) launch_trace_feat<kStackSmall, true>(features, w, parity);   // (the probe exists per feature set for the small stack only)
@@ -969,9 +977,9 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
 // at its own pace: nothing couples the groups but the work counter, so while the last long rays of one
 // group's trace pass keep a few waves busy, the other groups' kernels fill the rest of the chip. (Measured
 // with one group: the mean wave lives 0.41 of a trace pass — rt_debug_pass_timing.)
-hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
-                                   const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
-                                   const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing) {
+static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
+                                const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
+                                const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing, KernelTimes *kt) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const uint32_t blocks = pool.n_blocks;
     hipError_t e;
@@ -985,9 +993,10 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.max_list, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(pool.fault, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
     }
     const uint32_t trace_blocks = blocks / pool.segs;
-    int G = timing ? 1 : gs.n;
+    int G = (timing || kt) ? 1 : gs.n;
     if (G < 1) G = 1;
     if ((uint32_t)G > trace_blocks) G = (int)trace_blocks;
     WfLaunch w[kMaxGroups];
@@ -1023,7 +1032,19 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                 if ((e = hipMemsetAsync(pool.dbg, 0xFF, sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
                 if ((e = hipMemsetAsync(pool.dbg + 1, 0, 4 * sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
             }
-            launch_pass(w[g], iter[g] & 1u, stack_need, features, counters, timing != nullptr);
+            // (kernel times: event 2k before the shade pass of pair k, 2k+1 between its shade and trace pass, 2k+2 after)
+            hipEvent_t mid = nullptr;
+            if (kt) {
+                while (kt->ev.size() < 2 * (size_t)iterations + 3) {
+                    hipEvent_t ne = nullptr;
+                    if ((e = hipEventCreate(&ne)) != hipSuccess) return e;
+                    kt->ev.push_back(ne);
+                }
+                if (iterations == 0 && (e = hipEventRecord(kt->ev[0], w[g].stream)) != hipSuccess) return e;
+                mid = kt->ev[2 * iterations + 1];
+            }
+            launch_pass(w[g], iter[g] & 1u, stack_need, features, counters, timing != nullptr, mid);
+            if (kt && (e = hipEventRecord(kt->ev[2 * iterations + 2], w[g].stream)) != hipSuccess) return e;
             iter[g]++;
             iterations++;
         }
@@ -1088,7 +1109,36 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
     }
     for (int g = 0; g < G; g++)                 // (a drained group may still have an idle batch queued)
         if ((e = hipStreamSynchronize(w[g].stream)) != hipSuccess) return e;
+    if (kt) {                                   // device time of the shade passes and of the trace passes
+        kt->shade_ms = kt->trace_ms = 0.0;
+        for (uint32_t k = 0; k < iterations; k++) {
+            float a = 0.f, b = 0.f;
+            if ((e = hipEventElapsedTime(&a, kt->ev[2 * k], kt->ev[2 * k + 1])) != hipSuccess) return e;
+            if ((e = hipEventElapsedTime(&b, kt->ev[2 * k + 1], kt->ev[2 * k + 2])) != hipSuccess) return e;
+            kt->shade_ms += (double)a;
+            kt->trace_ms += (double)b;
+        }
+    }
     if (out_iterations) *out_iterations = iterations;
+    return hipSuccess;
+}
+
+hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
+                                   const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
+                                   const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing,
+                                   uint32_t *out_fault, KernelTimes *kt) {
+    hipError_t e = render_passes(scene, args, d_args, pool, stack_need, features, counters, gs, stream, out_iterations, timing, kt);
+    if (e != hipSuccess) {
+        // Passes may still be queued or running against the pool on the group streams: let them finish (best
+        // effort) before the caller sees the error and possibly frees or reuses the pool.
+        for (int g = 0; g < kMaxGroups; g++)
+            if (gs.stream[g]) (void)hipStreamSynchronize(gs.stream[g]);
+        (void)hipStreamSynchronize(stream);
+        return e;
+    }
+    uint32_t fault = 0;
+    if ((e = hipMemcpy(&fault, pool.fault, sizeof fault, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    if (out_fault) *out_fault = fault;
     return hipSuccess;
 }
 

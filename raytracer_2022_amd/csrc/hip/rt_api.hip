@@ -207,6 +207,21 @@ struct Validator {
     }
 };
 
+// The scene's buffers, pools and streams live on the device that was current at rt_scene_create. Every entry
+// point that touches them makes that device current for the call and puts the caller's back afterwards, so one
+// process may hold scenes on several GPUs (one host thread per scene and stream) whatever its current device is.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        RT_HIP(hipGetDevice(&prev));
+        if (prev != want) { RT_HIP(hipSetDevice(want)); switched = true; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 template <class T>
 T *upload(const T *src, uint64_t n, std::vector<void *> &owned) {
     // Never hand the kernels a null pool: an empty pool gets one zeroed element.
@@ -239,6 +254,11 @@ struct Workspace {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rt_stats *pending = nullptr;      // host stats to fill at rt_render_wait
     bool pending_counters = false;
+    KernelTimes kt;                   // RT_FLAG_KERNEL_TIMES
+    bool used_kt = false;
+    uint32_t used_chunk = 0, used_passes = 0;
+    uint64_t used_slots = 0;
+    uint32_t *rows_max = nullptr;     // device word: largest row id of the call being checked
 };
 
 } // namespace
@@ -257,6 +277,7 @@ struct rt_scene {
     int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
     double pass_timing[5] = {};       // of the last render with tuning bit 29 (rt_debug_pass_timing)
     int device = 0;
+    int n_cus = 0;                    // compute units of `device`
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
 };
@@ -307,6 +328,7 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     }
     if (slots <= w.pool_slots && depth <= w.pool_depth) { w.pool.n_blocks = blocks; w.pool.n_slots = w.pool_slots; return; }
     RT_HIP(hipStreamSynchronize(stream));
+    for (int g = 0; g < kMaxGroups; g++) RT_HIP(hipStreamSynchronize(w.gs.stream[g]));    // (passes of an earlier call that failed half-way)
     for (void *p : w.pool_owned) RT_HIP(hipFree(p));
     w.pool_owned.clear();
     w.pool_slots = 0; w.pool_depth = 0;
@@ -329,9 +351,31 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.n_active = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
     q.next_chunk = pool_alloc<uint32_t>(w, kMaxGroups);
     q.max_list = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
+    q.fault = pool_alloc<uint32_t>(w, 1);
     w.pool_dbg = pool_alloc<unsigned long long>(w, 8 + 2 * 65536);
     w.pool_slots = slots;
     w.pool_depth = depth;
+}
+
+// Largest of n device-resident row ids (rt_render_device's twin of rt_render's host-side range check).
+__global__ void __launch_bounds__(256) row_ids_max_kernel(const uint32_t *rows, uint32_t n, uint32_t *out) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = rows[i] > m ? rows[i] : m;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
+}
+void check_device_rows(Workspace &w, const rt_params *p, hipStream_t stream) {
+    if (p->n_rows == 0) return;
+    if (!w.rows_max) RT_HIP(hipMalloc((void **)&w.rows_max, sizeof(uint32_t)));
+    RT_HIP(hipMemsetAsync(w.rows_max, 0, sizeof(uint32_t), stream));
+    uint32_t blocks = (p->n_rows + 255u) / 256u;
+    hipLaunchKernelGGL(row_ids_max_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, p->row_ids, p->n_rows, w.rows_max);
+    RT_HIP(hipGetLastError());
+    uint32_t h = 0;
+    RT_HIP(hipMemcpyAsync(&h, w.rows_max, sizeof h, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    RT_REQUIRE((uint64_t)h < (uint64_t)p->height * p->n_frames, RT_ERR_INVALID, "rt_render_device: row id out of range");
 }
 
 // Enqueue one render on `stream`; row ids and output are device pointers.
@@ -353,6 +397,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     a.n_items = a.n_pixels * a.n_chunks;
     a.row_ids = d_rows;
     bool counters = stats && (p->flags & RT_FLAG_COUNTERS);
+    const bool want_kt = stats && (p->flags & RT_FLAG_KERNEL_TIMES) && sc->engine == 1;
     if (a.n_chunks > 1) {
         uint64_t bytes = a.n_items * 3 * sizeof(double);
         if (bytes > w.partial_bytes) {
@@ -373,8 +418,6 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     a.stats = counters ? w.stats : nullptr;
     if (sc->engine == 1) {
         // Wavefront engine: pool of path slots, shade / trace passes until it drains.
-        hipDeviceProp_t prop;
-        RT_HIP(hipGetDeviceProperties(&prop, sc->device));
         // Pool = segments of 4096 path slots (one shade workgroup each). The trace pass is a persistent grid of
         // kTraceBlocksPerCU workgroups per CU that draws on all segments' ray lists; the pool holds `segs` segments
         // per such workgroup (default 6: 31 M slots, ~58 GB with a depth-50 tape — measured optimum of 2.5-10 K
@@ -382,7 +425,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         uint32_t segs = (sc->node_quorum >> 16) & 0xFu;
         if (segs < 1) segs = 1;
         if (segs > 8) segs = 8;
-        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : (uint32_t)kTraceBlocksPerCU * (uint32_t)prop.multiProcessorCount * segs;
+        uint32_t max_blocks = sc->max_pool_blocks > 0 ? (uint32_t)sc->max_pool_blocks : (uint32_t)kTraceBlocksPerCU * (uint32_t)sc->n_cus * segs;
         // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
         uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
@@ -402,7 +445,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
         w.pool.segs = segs;
-        w.pool.n_cus = (uint32_t)prop.multiProcessorCount;
+        w.pool.n_cus = (uint32_t)sc->n_cus;
         const bool timing = (sc->node_quorum & (1u << 29)) != 0;
         w.gs.n = (int)((sc->node_quorum >> 24) & 0xFu);     // groups of segments passing independently (streams)
         if (w.gs.n < 1) w.gs.n = 1;
@@ -416,13 +459,17 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
         RT_HIP(hipEventRecord(w.ev0, stream));
         if (a.n_items > 0) {
+            uint32_t fault = 0;
             RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.gs, stream, &w.iterations,
-                                           timing ? sc->pass_timing : nullptr));
+                                           timing ? sc->pass_timing : nullptr, &fault, want_kt ? &w.kt : nullptr));
+            RT_REQUIRE(fault == 0, RT_ERR_DEVICE, "wavefront engine: a path slot reached the shade pass without having been traced (internal error; the frame is incomplete)");
             if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
         RT_HIP(hipEventRecord(w.ev1, stream));
         w.pending = stats;
         w.pending_counters = counters;
+        w.used_chunk = a.chunk; w.used_passes = w.iterations; w.used_slots = (uint64_t)w.pool.n_blocks * kSlotsPerBlock;
+        w.used_kt = want_kt && a.n_items > 0;
         return;
     }
     // Megakernel engine. Bounce tape: max_depth records of 4 doubles for every lane of the persistent grid.
@@ -449,6 +496,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     RT_HIP(hipEventRecord(w.ev1, stream));
     w.pending = stats;
     w.pending_counters = counters;
+    w.used_chunk = a.chunk; w.used_passes = 0; w.used_slots = 0; w.used_kt = false;
 }
 
 void finish(rt_scene *sc, hipStream_t stream) {
@@ -471,6 +519,8 @@ void finish(rt_scene *sc, hipStream_t stream) {
         float ms = 0.f;
         RT_HIP(hipEventElapsedTime(&ms, w.ev0, w.ev1));
         out.ms = (double)ms;
+        out.spp_chunk = w.used_chunk; out.passes = w.used_passes; out.pool_slots = w.used_slots;
+        if (w.used_kt) { out.trace_ms = w.kt.trace_ms; out.shade_ms = w.kt.shade_ms; }
         *w.pending = out;
         w.pending = nullptr;
     }
@@ -497,6 +547,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         rt_scene *sc = new rt_scene();
         try {
             RT_HIP(hipGetDevice(&sc->device));
+            RT_HIP(hipDeviceGetAttribute(&sc->n_cus, hipDeviceAttributeMultiprocessorCount, sc->device));
+            RT_REQUIRE(sc->n_cus > 0, RT_ERR_DEVICE, "rt_scene_create: device reports no compute units");
             SceneDev &s = sc->dev;
             s.nodes = upload(desc->nodes, desc->n_nodes, sc->owned);
             // Primitive pools go up with the slot kind of their material packed above the material index (pt_device.h).
@@ -549,9 +601,12 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
 int rt_scene_destroy(rt_scene *scene) {
     return guarded([&]() -> int {
         if (!scene) return RT_OK;
-        (void)hipDeviceSynchronize();
+        DeviceGuard guard(scene->device);
+        (void)hipDeviceSynchronize();                 // (every stream of the scene's device, the group streams included)
         for (auto &kv : scene->ws) {
             Workspace &w = kv.second;
+            if (w.rows_max) (void)hipFree(w.rows_max);
+            for (hipEvent_t ev : w.kt.ev) (void)hipEventDestroy(ev);
             if (w.work_counter) (void)hipFree(w.work_counter);
             if (w.stats) (void)hipFree(w.stats);
             if (w.partial) (void)hipFree(w.partial);
@@ -579,6 +634,8 @@ int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *par
     return guarded([&]() -> int {
         check_params(scene, cam, params);
         RT_REQUIRE(d_out_rgb_sum || params->n_rows == 0, RT_ERR_INVALID, "rt_render_device: output is null");
+        DeviceGuard guard(scene->device);
+        check_device_rows(workspace_for(scene, (hipStream_t)hip_stream), params, (hipStream_t)hip_stream);
         enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, (hipStream_t)hip_stream, stats);
         return RT_OK;
     });
@@ -587,6 +644,7 @@ int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *par
 int rt_render_wait(rt_scene *scene, void *hip_stream) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_render_wait: null scene");
+        DeviceGuard guard(scene->device);
         finish(scene, (hipStream_t)hip_stream);
         return RT_OK;
     });
@@ -599,6 +657,7 @@ int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params, do
         for (uint32_t i = 0; i < params->n_rows; i++)
             RT_REQUIRE(params->row_ids[i] < (uint64_t)params->height * params->n_frames, RT_ERR_INVALID, "rt_render: row id out of range");
         uint64_t n_values = (uint64_t)params->n_rows * params->width * 3;
+        DeviceGuard guard(scene->device);
         uint32_t *d_rows = nullptr;
         double *d_out = nullptr;
         int rc = RT_OK;

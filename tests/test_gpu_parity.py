@@ -188,6 +188,28 @@ def test_deep_stacks_select_the_larger_kernels(rt, O):
     assert e.value.code == F.RT_ERR_UNSUPPORTED
 
 
+def test_c5_mesh_at_its_benchmark_size(rt, O):
+    """BASELINE config 5 at the mesh size `bench.py --config c5` times: wwscene, param=3 — 1.05 M triangles in a
+    21-deep BVH under Translate<RotateY<Zoom<…>>> (scene.rs:408-412) — on a small image the oracle finishes in a
+    second. Counters and bits, with and without RT_FLAG_COUNTERS, running sum and one-sample items."""
+    s = rt.HostScene("wwscene", seed=2022, param=3)
+    assert s.desc.n_triangles > 1_000_000 and s.desc.n_nodes > 1_000_000
+    dev = rt.DeviceScene(s.desc)
+    assert 22 < dev.info()["stack_need"] <= 30
+    W, H, spp = 96, 54, 2
+    cam, bg = s.default_view(W / H)
+    rows = rt.shuffled_rows(H, 3)
+    for chunk in (0, 1):
+        p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
+        ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=os.cpu_count() or 4, want_stats=True)
+        assert st_ref.prim_tests[F.RT_KIND_TRIANGLE] > 100_000 and st_ref.prim_tests[F.RT_KIND_ZOOM] > 0
+        out, st = dev.render(cam, p, rows, want_stats=True)
+        assert st.as_dict() == st_ref.as_dict(), chunk
+        assert np.array_equal(bits(out), bits(ref)), chunk
+        assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), chunk       # the timed kernel variant
+        assert np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
+
+
 def test_node_step_variants(rt, O):
     """The traversal's short node step (min / max slabs, one exit test) is only taken where it provably
     equals AABB::hit (aabb.rs:15-32); everything else runs the literal restatement. Both against the oracle."""
