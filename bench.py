@@ -42,8 +42,8 @@ CONFIGS = {
     "c3": ("final_scene", 800, 800, 1000, "book-2 final scene 800x800x1000spp depth 50"),
     "c2": ("random_scene", 1200, 800, 500, "book-1 final scene (random spheres) 1200x800x500spp depth 50"),
     "c4": ("cornell_box", 600, 600, 1000, "book-3 Cornell box, MixturePdf, 600x600x1000spp depth 50"),
-    # 8-GPU config of BASELINE.json; the mesh is the Shuttle stand-in subdivided to ~1.05 M triangles
-    "c5": ("wwscene", 1920, 1080, 2000, "OBJ mesh scene (~1.05M triangles) + planet textures 1920x1080x2000spp depth 50"),
+    # 8-GPU config of BASELINE.json; the mesh is assets/Shuttle.obj subdivided three times (837 056 triangles)
+    "c5": ("wwscene", 1920, 1080, 2000, "OBJ mesh scene (Shuttle.obj x 3 subdivisions = 0.84M triangles) + planet textures 1920x1080x2000spp depth 50"),
 }
 SCENE_PARAM = {"c5": 3}
 
@@ -466,7 +466,9 @@ def main():
                        "pool_slots": int(s.pool_slots) if kernel_ms else None, "seed": args.seed,
                        "sharding": ("rows of an N-frame strip dealt cyclically (one frame's worth per GPU)" if args.scaling == "weak"
                                     else "rows of ONE frame dealt cyclically over the GPUs") + "; gather of row buffers to rank 0",
-                       "earth_texture": "assets/earthmap.ppm" if assets and os.path.exists(os.path.join(assets, "earthmap.ppm")) else "procedural stand-in"},
+                       "assets": ("assets/ (the reference's earthmap / planet JPEGs and Shuttle.obj)" if assets and os.path.exists(os.path.join(assets, "earthmap.jpg"))
+                                  else "procedural stand-ins (no assets directory)"),
+                       "triangles": int(scene.desc.n_triangles), "bvh_nodes": int(scene.desc.n_nodes)},
             "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
             "roofline": roof,
             "counters_rank0": counts,

@@ -20,8 +20,8 @@ typedef struct rtb_scene rtb_scene;   /* a built scene: owns the pools behind it
 /* scene::<name>() + BvhNode::new_list (main.rs:89-90) with a seeded stream.
  * name: random_scene | two_spheres | two_perlin_spheres | earth | simple_light |
  *       cornell_box | cornell_smoke | final_scene | wwscene (scene.rs:22-571).
- * assets_dir: where <stem>.ppm textures / Shuttle.obj live (NULL or "" = procedural
- * stand-ins). param: random_scene → half grid size (0 = 11, the reference's);
+ * assets_dir: where the <stem>.jpg (or .ppm) textures and Shuttle.obj live (NULL or "" =
+ * procedural stand-ins). param: random_scene → half grid size (0 = 11, the reference's);
  * wwscene → midpoint-subdivision levels of the model mesh. */
 int rtb_scene_build(const char *name, uint64_t seed, const char *assets_dir, int32_t param, rtb_scene **out);
 void rtb_scene_free(rtb_scene *scene);
@@ -49,6 +49,13 @@ int rtb_bvh_build(const uint32_t *leaf_refs, const double *boxes6, uint32_t n, u
 int rtb_fill_image(const double *rgb_sum, const uint32_t *row_ids, uint32_t n_rows, uint32_t width,
                    uint32_t height, int32_t spp, uint8_t *rgb8);
 int rtb_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+/* main.rs:213-221: JPEGEncoder::new_with_quality(file, IMAGE_QUALITY = 100).encode(img, W, H, RGB8) — baseline JPEG,
+ * 4:4:4, Annex-K tables scaled by the IJG quality rule. (`image 0.23.14` is not in /root/reference: the byte stream is
+ * this library's own, the decoded pixels agree with any conforming decoder.) */
+int rtb_write_jpeg(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height, int32_t quality);
+/* The decode step of ImageTexture::new (texture/mod.rs:90-93): a baseline JPEG or binary PPM file to RGB8 rows,
+ * top-down. out_rgb8 = NULL only queries the size. Texels may differ from jpeg-decoder 0.1.22's by an LSB. */
+int rtb_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *out_rgb8, uint64_t capacity);
 
 const char *rtb_last_error(void);
 /* sizeof of each ABI structure (binding layout check); returns how many there are. */

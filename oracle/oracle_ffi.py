@@ -111,6 +111,15 @@ def ray_color(desc, orig, direction, tm=0.0, background=(0, 0, 0), t_min=0.001, 
     return np.array(out[:])
 
 
+def texture_value(desc, tex, u, v, p):
+    """Texture::value(u, v, p) of texture `tex` (texture/mod.rs:25-139) → (r, g, b)."""
+    out = (C.c_double * 3)()
+    rc = lib().rto_texture_value(C.byref(desc), tex, float(u), float(v), _d(p), out)
+    if rc != 0:
+        raise RuntimeError("rto_texture_value: %s" % lib().rto_last_error().decode())
+    return np.array(out[:])
+
+
 def math_array(op, a, b=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     out = np.empty_like(a)

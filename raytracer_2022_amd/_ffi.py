@@ -157,7 +157,8 @@ ABI_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_wait", "rt_write_color",
     "rt_tonemap_device", "rt_last_error", "rt_abi_version",
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
-    "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_last_error", "rtb_abi_sizes",
+    "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
+    "rtb_last_error", "rtb_abi_sizes",
     "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing",
 ]
 
@@ -197,6 +198,8 @@ def lib():
     L.rtb_bvh_build.argtypes = [P(u32), P(dbl), u32, u64, P(rt_bvh_node), u32]
     L.rtb_fill_image.argtypes = [P(dbl), P(u32), u32, u32, u32, i32, P(C.c_uint8)]
     L.rtb_write_ppm.argtypes = [C.c_char_p, P(C.c_uint8), u32, u32]
+    L.rtb_write_jpeg.argtypes = [C.c_char_p, P(C.c_uint8), u32, u32, i32]
+    L.rtb_image_load.argtypes = [C.c_char_p, P(u32), P(u32), P(C.c_uint8), u64]
     L.rtb_last_error.restype = C.c_char_p
     L.rtb_abi_sizes.argtypes = [P(u32), u32]
     L.rt_debug_math_device.argtypes = [C.c_int, P(dbl), P(dbl), P(dbl), u64]

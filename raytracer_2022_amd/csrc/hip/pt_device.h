@@ -125,12 +125,15 @@ struct WfPool {
 };
 
 // Traversal-stack capacities the megakernel is instantiated for.
-constexpr int kStackSmall = 22;   // 22 KiB of LDS per workgroup; the lean kernels run five workgroups per CU (VGPR-bound)
+constexpr int kStackSmall = 22;   // 22 KiB of LDS per workgroup; the lean kernels run four workgroups per CU (VGPR-bound)
 constexpr int kStackMid = 30;     // million-triangle meshes need ~26 entries; built for four workgroups per CU
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
+// Four traversal workgroups per CU = 4 waves per SIMD = a budget of 128 VGPRs: the kernel then needs 116 and spills
+// nothing. Five (96 VGPRs, 27 spilled, 84 B of scratch per lane) measured 3 % slower in the same run, three 8-9 %
+// slower (profiles/r2_ab_occupancy.log): the kernel is bound by instruction issue far more than by latency.
 #ifndef RT2022_TRACE_BLOCKS_PER_CU
-#define RT2022_TRACE_BLOCKS_PER_CU 5
+#define RT2022_TRACE_BLOCKS_PER_CU 4
 #endif
 constexpr int kTraceBlocksPerCU = RT2022_TRACE_BLOCKS_PER_CU;   // resident traversal workgroups per CU the lean kernels are built for
 

@@ -582,13 +582,14 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     const uint32_t n_seg = pool.n_blocks;
     const uint32_t total_ids = ((pool.max_list[parity] + kChunk - 1u) / kChunk) * n_seg;
     // This wave's chunk — entries [base + taken, base + n) of pool.list — and "the counter has run out": per-wave
-    // state, kept in LDS rather than in four more live registers (the kernel has none to spare). Written by the
-    // wave's leader lane and read by whichever lanes publish next: volatile, so every access is a real ds_read /
-    // ds_write in program order — one wave's LDS operations complete in the order it issues them, and the compiler
-    // may not carry the words in registers from one round to the next.
-    __shared__ uint32_t chunk_lds[kBlock / 64][4];
-    volatile uint32_t *const cs = chunk_lds[tid >> 6];
-    if (lane < 4) cs[lane] = 0;
+    // state {base, n, taken, drained}, kept in LDS rather than in four more live registers. Written by the wave's
+    // leader lane and read by whichever lanes publish next, as ONE volatile 16-byte access each way: volatile, so
+    // every access is a real ds_read_b128 / ds_write_b128 in program order — one wave's LDS operations complete in
+    // the order it issues them, and the compiler may not carry the words in registers from one round to the next.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ u32x4 chunk_lds[kBlock / 64];
+    volatile u32x4 *const cs = &chunk_lds[tid >> 6];
+    if (lane == 0) *cs = (u32x4){0u, 0u, 0u, 0u};
     const bool probe = PROBE && pool.dbg != nullptr;                  // (rt_debug_pass_timing: a build of its own, all arms)
     unsigned long long t_start = 0, t_dry = 0;
     bool dry_seen = false;
@@ -841,8 +842,9 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             uint32_t need = (uint32_t)__popcll(m);
             uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             uint32_t entry_idx = 0xFFFFFFFFu;                         // index into pool.list of the entry this lane takes
-            uint32_t ch_base = cs[0], ch_n = cs[1], ch_taken = cs[2];
-            bool drained = cs[3] != 0;
+            const u32x4 cs_now = *cs;
+            uint32_t ch_base = cs_now.x, ch_n = cs_now.y, ch_taken = cs_now.z;
+            bool drained = cs_now.w != 0;
             for (;;) {
                 const uint32_t avail = ch_n - ch_taken;
                 if (entry_idx == 0xFFFFFFFFu) {
@@ -863,7 +865,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 ch_base = seg * (uint32_t)S + first;
                 ch_taken = 0;
             }
-            if ((int)lane == leader) { cs[0] = ch_base; cs[1] = ch_n; cs[2] = ch_taken; cs[3] = drained ? 1u : 0u; }
+            if ((int)lane == leader) *cs = (u32x4){ch_base, ch_n, ch_taken, drained ? 1u : 0u};
             if (probe && !dry_seen && drained) { dry_seen = true; t_dry = wall_clock64(); }
             if (entry_idx != 0xFFFFFFFFu) {
                 const uint32_t sbase = entry_idx & ~((uint32_t)S - 1u);

@@ -192,4 +192,29 @@ int rtb_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_
     });
 }
 
+int rtb_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *out_rgb8, uint64_t capacity) {
+    return guarded([&]() -> int {
+        if (!path || !width || !height) throw Error(RT_ERR_INVALID, "rtb_image_load: null argument");
+        std::vector<uint8_t> top;
+        load_image_file(path, *width, *height, top);
+        if (out_rgb8) {
+            if (capacity < top.size()) throw Error(RT_ERR_INVALID, "rtb_image_load: output buffer too small");
+            std::memcpy(out_rgb8, top.data(), top.size());
+        }
+        return RT_OK;
+    });
+}
+
+int rtb_write_jpeg(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height, int32_t quality) {
+    return guarded([&]() -> int {
+        std::vector<uint8_t> bytes;
+        if (!rgb8 || !jpeg_encode_rgb8(rgb8, width, height, quality, bytes)) throw Error(RT_ERR_INVALID, "rtb_write_jpeg: bad image");
+        FILE *f = path ? std::fopen(path, "wb") : nullptr;
+        if (!f) throw Error(RT_ERR_INVALID, std::string("rtb_write_jpeg: cannot create ") + (path ? path : "(null)"));   // File::create(..).unwrap(), main.rs:214
+        std::fwrite(bytes.data(), 1, bytes.size(), f);
+        std::fclose(f);
+        return RT_OK;
+    });
+}
+
 } // extern "C"

@@ -2,6 +2,8 @@
 // See scene_api.hpp for the mapping to the reference's types.
 #include "scene_api.hpp"
 
+#include <iterator>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -102,19 +104,34 @@ static void ppm_skip(std::istream &in) {
     }
 }
 
-ImageTexture::ImageTexture(const std::string &filename) {
+void load_image_file(const std::string &filename, uint32_t &w, uint32_t &h, std::vector<uint8_t> &top) {
     std::ifstream in(filename, std::ios::binary);
     if (!in) throw Error(RT_ERR_INVALID, "ImageTexture::new: cannot open " + filename);   // image::open(..).unwrap()
+    int b0 = in.get(), b1 = in.peek();
+    in.seekg(0);
+    if (b0 == 0xFF && b1 == 0xD8) {                                      // JPEG: texture/mod.rs:90-93
+        std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        std::string err;
+        if (!jpeg_decode_rgb8(bytes.data(), bytes.size(), w, h, top, err)) throw Error(RT_ERR_INVALID, "ImageTexture::new: " + filename + ": " + err);
+        return;
+    }
     std::string magic;
     in >> magic;
-    if (magic != "P6") throw Error(RT_ERR_INVALID, "ImageTexture::new: " + filename + " is not a binary PPM (P6)");
-    uint32_t w = 0, h = 0, maxv = 0;
+    if (magic != "P6") throw Error(RT_ERR_INVALID, "ImageTexture::new: " + filename + " is neither a JPEG nor a binary PPM (P6)");
+    uint32_t maxv = 0;
+    w = h = 0;
     ppm_skip(in); in >> w; ppm_skip(in); in >> h; ppm_skip(in); in >> maxv;
     in.get();
     if (!in || w == 0 || h == 0 || maxv != 255) throw Error(RT_ERR_INVALID, "ImageTexture::new: bad PPM header in " + filename);
-    std::vector<uint8_t> top((size_t)w * h * 3);
+    top.resize((size_t)w * h * 3);
     in.read((char *)top.data(), (std::streamsize)top.size());
     if ((size_t)in.gcount() != top.size()) throw Error(RT_ERR_INVALID, "ImageTexture::new: truncated PPM " + filename);
+}
+
+ImageTexture::ImageTexture(const std::string &filename) {
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> top;
+    load_image_file(filename, w, h, top);
     *this = ImageTexture(w, h, top.data());
 }
 

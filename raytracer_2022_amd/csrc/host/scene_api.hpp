@@ -96,8 +96,8 @@ struct NoiseTexture : Texture {                      // texture/mod.rs:62-79
 struct ImageTexture : Texture {                      // texture/mod.rs:81-139
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> pixel_color;                // RGB8, bottom-up rows (mod.rs:94-99)
-    // ImageTexture::new(filename): binary PPM (P6, maxval 255) — the container has
-    // no JPEG decoder library; tools/make_textures.py converts the reference's JPEGs.
+    // ImageTexture::new(filename), texture/mod.rs:89-107: a baseline JPEG (decoded by host/jpeg.cpp — the
+    // reference's `image::open`) or a binary PPM (P6, maxval 255).
     explicit ImageTexture(const std::string &filename);
     // Top-down RGB8 rows as an image decoder yields them; flipped here like mod.rs:94-99.
     ImageTexture(uint32_t w, uint32_t h, const uint8_t *rgb_top_down);
@@ -332,6 +332,12 @@ SceneOut wwscene(HostRng &rng, const SceneAssets &assets, int shuttle_subdiv);  
 
 // Procedural RGB8 stand-in (top-down rows) used when an asset file is absent.
 std::vector<uint8_t> procedural_planet_rgb8(uint32_t w, uint32_t h, uint32_t variant);
+
+// host/jpeg.cpp: baseline JPEG -> RGB8 (rows top-down), and RGB8 -> baseline JPEG at an IJG quality (main.rs:213-221 uses 100).
+bool jpeg_decode_rgb8(const uint8_t *data, size_t size, uint32_t &width, uint32_t &height, std::vector<uint8_t> &rgb, std::string &err);
+bool jpeg_encode_rgb8(const uint8_t *rgb, uint32_t width, uint32_t height, int quality, std::vector<uint8_t> &out);
+// The decode step of ImageTexture::new: JPEG or binary PPM file -> RGB8 rows, top-down. Throws Error.
+void load_image_file(const std::string &filename, uint32_t &width, uint32_t &height, std::vector<uint8_t> &rgb_top_down);
 
 // main.rs:93-99: Fisher-Yates shuffle of the row ids.
 std::vector<uint32_t> shuffled_rows(uint32_t image_height, HostRng &rng);

@@ -8,8 +8,8 @@
 //    scenes return lights = ∅ (cosine-only mode of the integrator) and scenes lit
 //    by one emissive rect return that rect un-flipped, as cornell_box does
 //    (scene.rs:170-193).
-//  * image textures come from binary PPM files (tools/make_textures.py) or, when
-//    the file is absent, from a procedural stand-in of the same size.
+//  * image textures come from <assets>/<stem>.jpg (the reference's own files, decoded by host/jpeg.cpp) or
+//    <stem>.ppm or, when neither is there, from a procedural stand-in of the same size.
 #include "scene_api.hpp"
 
 #include <cstdio>
@@ -38,11 +38,12 @@ std::vector<uint8_t> procedural_planet_rgb8(uint32_t w, uint32_t h, uint32_t var
 }
 
 static std::shared_ptr<ImageTexture> load_image(const SceneAssets &assets, const char *stem, uint32_t w, uint32_t h, uint32_t variant) {
-    if (!assets.dir.empty()) {
-        std::string path = assets.dir + "/" + stem + ".ppm";
-        std::ifstream probe(path, std::ios::binary);
-        if (probe.good()) return std::make_shared<ImageTexture>(path);
-    }
+    if (!assets.dir.empty())
+        for (const char *ext : {".jpg", ".ppm"}) {                      // the reference opens source/<stem>.jpg (scene.rs:128,331,479-497)
+            std::string path = assets.dir + "/" + stem + ext;
+            std::ifstream probe(path, std::ios::binary);
+            if (probe.good()) return std::make_shared<ImageTexture>(path);
+        }
     auto px = procedural_planet_rgb8(w, h, variant);
     return std::make_shared<ImageTexture>(w, h, px.data());
 }

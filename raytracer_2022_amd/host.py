@@ -49,6 +49,21 @@ def fill_image(rgb_sum, row_ids, width, height, spp):
     return img
 
 
+def load_image(path):
+    """ImageTexture::new's decode step (texture/mod.rs:90-93): baseline JPEG or binary PPM → (h, w, 3) uint8, rows top-down."""
+    w, h = C.c_uint32(), C.c_uint32()
+    F.check(F.lib().rtb_image_load(path.encode(), C.byref(w), C.byref(h), None, 0))
+    img = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    F.check(F.lib().rtb_image_load(path.encode(), C.byref(w), C.byref(h), img.ctypes.data_as(C.POINTER(C.c_uint8)), img.size))
+    return img
+
+
+def write_jpeg(path, rgb8, quality=100):
+    """main.rs:213-221: the finished image as a baseline JPEG (IMAGE_QUALITY = 100 in the reference)."""
+    img = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    F.check(F.lib().rtb_write_jpeg(path.encode(), img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[1], img.shape[0], quality))
+
+
 def make_params(width, height, spp, max_depth=50, background=(0.0, 0.0, 0.0), seed=2022, n_frames=1,
                 spp_chunk=0, flags=0, t_min=0.001):
     p = F.rt_params()

@@ -1,0 +1,139 @@
+"""Asset ingestion either side of the hot path and image output (f3), host only:
+ImageTexture::new's decode + row flip (texture/mod.rs:89-107), the OBJ → Triangle list of get_shuttle
+(scene.rs:364-414, tobj semantics), the JPEG writer of main.rs:213-221.
+
+Third-party arithmetic is parity unpinned here: `jpeg-decoder 0.1.22` and `tobj 3.2.2` are not in /root/reference.
+The JPEG decoder is held to libjpeg-turbo (PIL) within a stated bound instead; the OBJ reader to hand-computed values."""
+import ctypes as C
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from raytracer_2022_amd import _ffi as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ASSETS = os.path.join(ROOT, "assets")
+SMALL = os.path.join(ROOT, "tests", "fixtures", "assets_small")
+
+# crc32 of the decoded RGB8 bytes (rows top-down) of the committed textures: a regression pin of host/jpeg.cpp
+DECODED_CRC = {"earthmap.jpg": (1024, 512), "Jupiter.jpg": (1024, 512), "Mars.jpg": (800, 383), "Saturn.jpg": (1280, 640)}
+
+
+def desc_array(ptr, n, ctype):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)) if n else np.zeros(0)
+
+
+def test_ppm_texture_is_stored_bottom_up(rt):
+    """texture/mod.rs:94-99: pixel_color row j = image row height-1-j; texel (i, j) at 3*(j*width+i)."""
+    s = rt.HostScene("earth", seed=1, assets_dir=SMALL)
+    d = s.desc
+    assert d.n_images == 1 and d.images[0].width == 4 and d.images[0].height == 2
+    data = np.ctypeslib.as_array(d.image_data, shape=(d.image_data_bytes,))
+    off = d.images[0].offset
+    stored = data[off:off + 24].reshape(2, 4, 3)
+    top_down = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]],
+                         [[40, 50, 60], [70, 80, 90], [100, 110, 120], [250, 251, 252]]], dtype=np.uint8)
+    assert np.array_equal(stored, top_down[::-1])
+    assert np.array_equal(rt.load_image(os.path.join(SMALL, "earthmap.ppm")), top_down)
+
+
+def test_image_texture_lookup_on_the_fixture(rt, O):
+    """ImageTexture::value (mod.rs:110-139) through the oracle on the 4x2 fixture: u → column, v → stored row
+    (so v = 1 is the top row of the file), truncation, clamp at the far edge, scale 1/255.999."""
+    s = rt.HostScene("earth", seed=1, assets_dir=SMALL)
+    tex = [i for i in range(s.desc.n_textures) if s.desc.textures[i].kind == F.RT_TEX_IMAGE][0]
+    for (u, v), rgb in {(0.0, 0.99): (255, 0, 0), (0.26, 0.99): (0, 255, 0), (1.0, 1.0): (10, 20, 30),
+                        (0.0, 0.0): (40, 50, 60), (0.76, 0.49): (250, 251, 252), (0.51, 0.51): (0, 0, 255)}.items():
+        got = O.texture_value(s.desc, tex, u, v, (0.0, 0.0, 0.0))
+        assert np.array_equal(np.asarray(got).view(np.uint64), (np.array(rgb, dtype=np.float64) * (1.0 / 255.999)).view(np.uint64)), (u, v)
+
+
+def test_obj_reader_has_tobj_semantics(rt):
+    """scene.rs:368-398: positions parsed as f32 and widened to f64, faces fan-triangulated in file order,
+    v/vt/vn triplets and negative (relative) indices resolved, unknown statements ignored."""
+    s = rt.HostScene("wwscene", seed=3, assets_dir=SMALL)
+    d = s.desc
+    tris = [(tuple(t.a), tuple(t.b), tuple(t.c)) for t in (d.triangles[i] for i in range(d.n_triangles))]
+    f32 = lambda *xs: tuple(float(np.float32(x)) for x in xs)
+    v = [f32(0.1, 0.2, 0.3), f32(1.1, 0.2, 0.3), f32(1.1, 1.2, 0.3), f32(0.1, 1.2, 0.3), f32(0.5, 0.7, 1.33333333333)]
+    assert v[0][0] != 0.1 and v[4][2] != 1.33333333333                      # (the coordinates really are rounded through f32)
+    want = [(v[0], v[1], v[2]),                                             # f 1/1/1 2/2/1 3/1/1
+            (v[0], v[1], v[2]), (v[0], v[2], v[3]),                         # the quad, as a fan
+            (v[4], v[0], v[1]),                                             # f -1//1 -5//1 -4//1
+            (v[3], v[2], v[4])]                                             # f 4 3 5
+    for t in want:
+        assert tris.count(t) >= want.count(t), t
+    # the model = those five triangles; the rest of the pool is the Ship stand-in (synthetic, 2048 triangles)
+    assert d.n_triangles == len(want) + 2048
+    # and it sits under Translate<RotateY<Zoom<BvhNode>>> (scene.rs:408-412)
+    kinds = sorted(int(d.xforms[i].kind) for i in range(d.n_xforms))
+    assert kinds.count(F.RT_KIND_ZOOM) == 2 and kinds.count(F.RT_KIND_ROTATE_Y) == 2 and kinds.count(F.RT_KIND_TRANSLATE) == 2
+
+
+def test_missing_and_broken_asset_files(rt, tmp_path):
+    (tmp_path / "earthmap.ppm").write_bytes(b"P6\n4 2\n255\n" + b"\x00" * 5)           # truncated
+    with pytest.raises(rt.RtError):
+        rt.HostScene("earth", seed=1, assets_dir=str(tmp_path))
+    (tmp_path / "earthmap.ppm").unlink()
+    (tmp_path / "earthmap.jpg").write_bytes(b"\xff\xd8\xff\xd9")                        # a JPEG with no frame
+    with pytest.raises(rt.RtError):
+        rt.HostScene("earth", seed=1, assets_dir=str(tmp_path))
+    with pytest.raises(rt.RtError):
+        rt.load_image(str(tmp_path / "nothing.jpg"))
+    # no file at all: the documented procedural stand-in of the reference texture's size
+    s = rt.HostScene("earth", seed=1, assets_dir=str(tmp_path / "empty"))
+    assert s.desc.images[0].width == 1024 and s.desc.images[0].height == 512
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="assets/ not present")
+def test_jpeg_decoder_against_libjpeg(rt):
+    """host/jpeg.cpp on the reference's four textures vs libjpeg-turbo (PIL): different IDCT and upsampling roundings
+    may move a texel by a few LSB; anything structural (Huffman, dequantisation, MCU order, 4:2:0 siting, the 383-row
+    partial MCU of Mars.jpg) would show as a large error."""
+    Image = pytest.importorskip("PIL.Image")
+    for name, (w, h) in DECODED_CRC.items():
+        path = os.path.join(ASSETS, name)
+        mine = rt.load_image(path)
+        assert mine.shape == (h, w, 3)
+        ref = np.asarray(Image.open(path).convert("RGB"))
+        d = np.abs(mine.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= 4 and d.mean() < 0.1, (name, d.max(), d.mean())
+
+
+@pytest.mark.skipif(not os.path.isdir(ASSETS), reason="assets/ not present")
+def test_scene_builders_read_the_committed_assets(rt):
+    """earth / final_scene take earthmap.jpg, wwscene the three planets and Shuttle.obj (scene.rs:128,331,366,479-497);
+    param subdivides the model (13 079 → 837 056 triangles at 3)."""
+    e = rt.HostScene("earth", seed=2022, assets_dir=ASSETS)
+    assert (e.desc.images[0].width, e.desc.images[0].height) == (1024, 512)
+    top = rt.load_image(os.path.join(ASSETS, "earthmap.jpg"))
+    data = np.ctypeslib.as_array(e.desc.image_data, shape=(e.desc.image_data_bytes,))
+    assert np.array_equal(data[:1024 * 512 * 3].reshape(512, 1024, 3), top[::-1])
+    w = rt.HostScene("wwscene", seed=2022, assets_dir=ASSETS)
+    assert w.desc.n_triangles == 13079 + 2048
+    assert sorted((w.desc.images[i].width, w.desc.images[i].height) for i in range(3)) == [(800, 383), (1024, 512), (1280, 640)]
+    w1 = rt.HostScene("wwscene", seed=2022, assets_dir=ASSETS, param=1)
+    assert w1.desc.n_triangles == 13079 * 4 + 2048
+
+
+def test_jpeg_writer_round_trip(rt, tmp_path):
+    """main.rs:213-221 at IMAGE_QUALITY = 100: what comes back from a decoder is the image to within the DCT's rounding."""
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:45, 0:70]
+    img = np.stack([(xx * 3 + yy) % 256, (yy * 5) % 256, rng.integers(0, 256, (45, 70))], axis=-1).astype(np.uint8)
+    path = str(tmp_path / "out.jpg")
+    rt.write_jpeg(path, img, 100)
+    back = rt.load_image(path)                               # this library's own decoder
+    assert back.shape == img.shape
+    assert np.abs(back.astype(np.int32) - img.astype(np.int32)).max() <= 4
+    try:
+        from PIL import Image
+        ref = np.asarray(Image.open(path).convert("RGB"))   # and an independent one
+        assert np.abs(ref.astype(np.int32) - img.astype(np.int32)).max() <= 4
+        assert np.abs(ref.astype(np.int32) - back.astype(np.int32)).max() <= 3
+    except ImportError:
+        pass
+    rt.write_jpeg(path, img, 50)
+    assert os.path.getsize(path) < img.size and np.abs(rt.load_image(path).astype(np.int32) - img).mean() < 40

@@ -188,12 +188,20 @@ def test_deep_stacks_select_the_larger_kernels(rt, O):
     assert e.value.code == F.RT_ERR_UNSUPPORTED
 
 
-def test_c5_mesh_at_its_benchmark_size(rt, O):
-    """BASELINE config 5 at the mesh size `bench.py --config c5` times: wwscene, param=3 — 1.05 M triangles in a
-    21-deep BVH under Translate<RotateY<Zoom<…>>> (scene.rs:408-412) — on a small image the oracle finishes in a
-    second. Counters and bits, with and without RT_FLAG_COUNTERS, running sum and one-sample items."""
-    s = rt.HostScene("wwscene", seed=2022, param=3)
-    assert s.desc.n_triangles > 1_000_000 and s.desc.n_nodes > 1_000_000
+ASSETS = os.path.join(os.path.dirname(HERE), "assets")
+
+
+@pytest.mark.parametrize("with_assets", [True, False])
+def test_c5_mesh_at_its_benchmark_size(rt, O, with_assets):
+    """BASELINE config 5 at the mesh size `bench.py --config c5` times: wwscene, param=3 — the reference's Shuttle.obj
+    (assets/) subdivided three times, 837 056 + 2 048 triangles, with the planets' JPEG textures; and the
+    1.05 M-triangle synthetic stand-in used when no assets directory is given — each in a ~20-deep BVH under
+    Translate<RotateY<Zoom<…>>> (scene.rs:408-412), on a small image the oracle finishes in a second. Counters and bits,
+    with and without RT_FLAG_COUNTERS, running sum and one-sample items."""
+    if with_assets and not os.path.isdir(ASSETS):
+        pytest.skip("assets/ not present")
+    s = rt.HostScene("wwscene", seed=2022, param=3, assets_dir=ASSETS if with_assets else None)
+    assert s.desc.n_triangles == (837056 + 2048 if with_assets else 1050624) and s.desc.n_nodes > 800_000
     dev = rt.DeviceScene(s.desc)
     assert 22 < dev.info()["stack_need"] <= 30
     W, H, spp = 96, 54, 2
@@ -207,6 +215,28 @@ def test_c5_mesh_at_its_benchmark_size(rt, O):
         assert st.as_dict() == st_ref.as_dict(), chunk
         assert np.array_equal(bits(out), bits(ref)), chunk
         assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), chunk       # the timed kernel variant
+        assert np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
+
+
+@pytest.mark.parametrize("scene,W,H,spp,param", [("earth", 64, 40, 4, 0), ("final_scene", 72, 72, 4, 0), ("wwscene", 80, 45, 3, 0)])
+def test_scenes_with_the_committed_assets(rt, O, scene, W, H, spp, param):
+    """The builders reading the reference's own input files (assets/: four JPEG textures through host/jpeg.cpp, Shuttle.obj
+    through the OBJ reader) instead of the procedural stand-ins: what `bench.py` times. ImageTexture::value on real texels
+    (texture/mod.rs:110-139), 13 079 real triangles (scene.rs:364-414)."""
+    if not os.path.isdir(ASSETS):
+        pytest.skip("assets/ not present")
+    s = rt.HostScene(scene, seed=2022, assets_dir=ASSETS, param=param)
+    assert s.desc.n_images >= 1 and s.desc.image_data_bytes >= 800 * 383 * 3
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022)
+    rows = rt.shuffled_rows(H, 9)
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=os.cpu_count() or 4, want_stats=True)
+    for engine in ("wavefront", "mega"):
+        dev = rt.DeviceScene(s.desc)
+        dev.set_engine(engine)
+        out, st = dev.render(cam, p, rows, want_stats=True)
+        assert st.as_dict() == st_ref.as_dict(), engine
+        assert np.array_equal(bits(out), bits(ref)), engine
         assert np.array_equal(rt.write_color(out, spp), O.write_color(ref, spp))
 
 

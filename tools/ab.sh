@@ -3,7 +3,7 @@
 # (RT2022_LIB selects the build) and prints value / ms per step for each.
 for so in raytracer_2022_amd/variants/*.so; do
   n=$(basename $so .so)
-  RT2022_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu-baseline "$@" > gpurun_out/ab_$n.log 2>&1 || { echo "$n: bench failed, stopping"; tail -3 gpurun_out/ab_$n.log; exit 1; }
+  RT2022_LIB=$PWD/$so timeout -k 10 200 python bench.py --no-cpu-baseline --no-pmc "$@" > gpurun_out/ab_$n.log 2>&1 || { echo "$n: bench failed, stopping"; tail -3 gpurun_out/ab_$n.log; exit 1; }
   python3 - "$n" gpurun_out/ab_$n.log <<'PY'
 import sys, json
 n, f = sys.argv[1], sys.argv[2]
