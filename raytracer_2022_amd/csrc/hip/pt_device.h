@@ -12,6 +12,17 @@
 
 namespace rt2022 {
 
+// ConstantMedium as the traversal kernel wants it: one 64-byte record = one fetch, with the boundary's data inline
+// when the boundary is a plain Sphere (the fog and the subsurface ball of the final scene) — rt_medium alone would cost
+// a dependent second fetch of the sphere record.
+struct MediumDev {
+    double center[3], radius;          // boundary sphere (zeros when the boundary is something else)
+    double neg_inv_density;
+    uint32_t boundary, mat;            // mat = material index | slot kind << kMatKindShift, like the primitive pools
+    uint32_t sphere_boundary;          // 1: the boundary is a plain Sphere
+    uint32_t _pad[3];
+};
+
 // Pointers into HBM, one pool per kind (layouts = include/rt2022.h).
 struct SceneDev {
     const rt_bvh_node *nodes;
@@ -33,6 +44,8 @@ struct SceneDev {
     const rt_perlin *perlins;
     uint32_t root;
     uint32_t n_lights;
+    const MediumDev *media_dev;        // [n_media], traversal kernel's view of `media`
+    uint32_t media_mode;               // 0: no medium has a plain-sphere boundary, 1: all have, 2: mixed (look at the record)
 };
 
 // Counter block in HBM (same order as rt_stats' integer fields).

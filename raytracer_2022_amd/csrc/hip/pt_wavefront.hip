@@ -488,6 +488,9 @@ struct TLane {
     Chain ctx;
     Chain win_chain;
     uint32_t win_leaf, win_face;
+    uint32_t win_mat;      // material word of the winning leaf (index | slot kind << kMatKindShift), taken from the record at hand
+    double stash_ix, stash_iz;   // 1/d.x, 1/d.z of the frame a RotateY was entered from (they change only there) ...
+    uint32_t stash_level;        // ... and that frame's mover depth (0xFFFFFFFF: nothing stashed)
     uint32_t slot;
     uint32_t steps;        // node steps of this ray
     int sp;
@@ -504,18 +507,46 @@ struct TStack {
 };
 
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
+// Records are fetched whole and at once — a few 16-byte loads issued back to back and waited for together — never
+// field by field as the arithmetic gets to them: left to itself the compiler sinks each field's load into the branch
+// that uses it, and an arm like Boxes::hit then waits for memory six to ten times in a row (seen in the ISA). The empty
+// asm pins the value: the load cannot move below it, and everything pinned together shares one wait.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // (records whose size is 8 mod 16)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
+// The fast node step applies (see there): every 1/d finite and non-zero, origin finite, boxes plain.
+RT_DEV void t_flags(TLane &L, bool boxes_plain) {
+    L.plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
+              L.inv.z != 0.0 && t_finite(L.cur.o.x) && t_finite(L.cur.o.y) && t_finite(L.cur.o.z);
+}
 RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
     L.inv = Vec3(1.0 / c.d.x, 1.0 / c.d.y, 1.0 / c.d.z);
     L.a_len = c.d.length_sqr();
-    L.plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
-              L.inv.z != 0.0 && t_finite(c.o.x) && t_finite(c.o.y) && t_finite(c.o.z);
+    t_flags(L, boxes_plain);
 }
 RT_DEV double t_hi(const TLane &L) { return L.med_ref ? L.sub_closest : L.closest; }
-RT_DEV void t_accept(TLane &L, double t, uint32_t face) {
+RT_DEV void t_accept(TLane &L, double t, uint32_t face, uint32_t mat_word) {
     if (L.med_ref) { L.sub_closest = t; L.sub_found = true; return; }
     L.closest = t;
-    L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx;
+    L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx; L.win_mat = mat_word;
+}
+// Boxes::hit over six sides given by value (boxes.rs:24-66,80-82 + mod.rs:90-100): box_t of pt_common.hpp, fed from
+// registers.
+RT_DEV bool t_box(double p0x, double p0y, double p0z, double p1x, double p1y, double p1z, const XRay &r, double t_min, double t_max,
+                  double &t, uint32_t &face) {
+    bool any = false;
+    double closest = t_max, tt;
+    if (rect_t(RT_RECT_XY, p0x, p1x, p0y, p1y, p1z, r, t_min, closest, tt)) { closest = tt; face = 0; any = true; }
+    if (rect_t(RT_RECT_XY, p0x, p1x, p0y, p1y, p0z, r, t_min, closest, tt)) { closest = tt; face = 1; any = true; }
+    if (rect_t(RT_RECT_XZ, p0x, p1x, p0z, p1z, p1y, r, t_min, closest, tt)) { closest = tt; face = 2; any = true; }
+    if (rect_t(RT_RECT_XZ, p0x, p1x, p0z, p1z, p0y, r, t_min, closest, tt)) { closest = tt; face = 3; any = true; }
+    if (rect_t(RT_RECT_YZ, p0y, p1y, p0z, p1z, p1x, r, t_min, closest, tt)) { closest = tt; face = 4; any = true; }
+    if (rect_t(RT_RECT_YZ, p0y, p1y, p0z, p1z, p0x, r, t_min, closest, tt)) { closest = tt; face = 5; any = true; }
+    t = closest;
+    return any;
 }
 // L.top has just been set: label it. The two cheap steps of ConstantMedium::hit — start the first
 // boundary query, turn the first into the second (constantmedium.rs:50-51) — are taken on the spot
@@ -527,20 +558,20 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
             if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM) {               // a medium leaf: boundary.hit(r, -inf, inf)
                 // (a boundary that is one plain sphere — the fog and the subsurface ball of the final scene —
                 // is not traversed at all: the medium arm does both queries and the finish in one turn)
-                if (RT_REF_KIND(s.media[RT_REF_INDEX(L.top)].boundary) == RT_KIND_SPHERE) break;
+                if (s.media_mode == 1u || (s.media_mode == 2u && s.media_dev[RT_REF_INDEX(L.top)].sphere_boundary)) break;
                 cnt.prim(RT_KIND_MEDIUM);
                 L.med_ref = L.top;
                 L.t_lo = -rtm::INF;
                 L.sub_closest = rtm::INF; L.sub_found = false;
                 st.push(L, REF_MED1);
-                L.top = s.media[RT_REF_INDEX(L.top)].boundary;
+                L.top = s.media_dev[RT_REF_INDEX(L.top)].boundary;
             } else if (L.top == REF_MED1) {
                 if (L.sub_found) {                                    // boundary.hit(r, rec1.t + 0.0001, inf)
                     L.med_t1 = L.sub_closest;
                     L.t_lo = L.med_t1 + 0.0001;
                     L.sub_closest = rtm::INF; L.sub_found = false;
                     st.push(L, REF_MED2);
-                    L.top = s.media[RT_REF_INDEX(L.med_ref)].boundary;
+                    L.top = s.media_dev[RT_REF_INDEX(L.med_ref)].boundary;
                 } else {
                     L.med_ref = 0; L.t_lo = t_min;
                     L.top = st.pop(L);
@@ -566,11 +597,17 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
     __shared__ uint32_t stack_lds[STACK * kBlock];
+    // The world ray of every lane's current path, [component][lane] (12 KiB where the scene has movers, 48 bytes
+    // otherwise): leaving a mover restarts from it (a ray_at_level of the enclosing frame) without going back to HBM.
+    // (The deeper-stack variants have no LDS to spare at four workgroups per CU: they fetch it from the pool again.)
+    constexpr bool kStash = (FEAT & kFeatMovers) != 0 && STACK <= kStackSmall;
+    __shared__ double wray_lds[kStash ? 6 * kBlock : 6];
     const PoolView pv{pool};
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
     TStack<STACK> st{stack_lds + tid};
+    double *const wray = wray_lds + (kStash ? tid : 0u);
 
     // Work of a pass = the ray lists of all segments (written by the preceding shade pass), cut into chunks of
     // kChunk entries and numbered slice-major: chunk id -> (slice = id / segments, segment = id % segments), so
@@ -600,7 +637,8 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
     L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
-    L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0;
+    L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0; L.win_mat = 0;
+    L.stash_ix = 0.0; L.stash_iz = 0.0; L.stash_level = 0xFFFFFFFFu;
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
     constexpr int sphere_reps = 2;                                    // (a span-2 leaf pair in one turn)
     constexpr int tail_factor = 2;
@@ -687,21 +725,25 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
         } else if (best == OP_NODE) {
             cnt.node();
             L.steps++;
-            const rt_bvh_node &n = s.nodes[RT_REF_INDEX(L.top)];
+            const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + RT_REF_INDEX(L.top));
+            f64x2 n0 = np[0], n1 = np[1], n2 = np[2];
+            u32x4 n3 = reinterpret_cast<const u32x4 *>(np)[3];
+            t_pin(n0); t_pin(n1); t_pin(n2); t_pin(n3);
+            const double bmin[3] = {n0.x, n0.y, n1.x}, bmax[3] = {n1.y, n2.x, n2.y};
             double tmn = L.t_lo, tmx = t_hi(L);
             bool miss = false;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 double inv_d = L.inv[i];
-                double t0 = (n.bmin[i] - L.cur.o[i]) * inv_d;
-                double t1 = (n.bmax[i] - L.cur.o[i]) * inv_d;
+                double t0 = (bmin[i] - L.cur.o[i]) * inv_d;
+                double t1 = (bmax[i] - L.cur.o[i]) * inv_d;
                 if (inv_d < 0.0) { double tmp = t0; t0 = t1; t1 = tmp; }
                 tmn = t0 > tmn ? t0 : tmn;
                 tmx = t1 < tmx ? t1 : tmx;
                 miss = miss || (tmx <= tmn);
             }
             if (!miss) {
-                uint32_t left = n.left, right = n.right, lk = RT_REF_KIND(left);
+                uint32_t left = n3.x, right = n3.y, lk = RT_REF_KIND(left);
                 if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
                 else st.push(L, right);
                 L.top = left;
@@ -719,31 +761,64 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 cnt.prim(kind);
                 Vec3 center;
                 double radius;
-                if (kind == RT_KIND_SPHERE) { const rt_sphere &q = s.spheres[idx]; center = ld3(q.center); radius = q.radius; }
-                else { const rt_moving_sphere &q = s.moving_spheres[idx]; center = moving_center(q, L.tm); radius = q.radius; }
+                uint32_t mat_word;
+                if (kind == RT_KIND_SPHERE) {                         // rt_sphere, 40 B: center, radius, mat
+                    const f64x2_a8 *qp = reinterpret_cast<const f64x2_a8 *>(s.spheres + idx);
+                    f64x2 q0 = qp[0], q1 = qp[1];
+                    mat_word = s.spheres[idx].mat;
+                    t_pin(q0); t_pin(q1); t_pin(mat_word);
+                    center = Vec3(q0.x, q0.y, q1.x); radius = q1.y;
+                } else {                                              // rt_moving_sphere, 80 B: center0, center1, time0, time1, radius, mat
+                    const f64x2 *qp = reinterpret_cast<const f64x2 *>(s.moving_spheres + idx);
+                    f64x2 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3], q4 = qp[4];
+                    t_pin(q0); t_pin(q1); t_pin(q2); t_pin(q3); t_pin(q4);
+                    const Vec3 c0(q0.x, q0.y, q1.x), c1(q1.y, q2.x, q2.y);
+                    center = c0 + (c1 - c0) * ((L.tm - q3.x) / (q3.y - q3.x));   // MovingSphere::center, sphere.rs:124-127
+                    radius = q4.x;
+                    mat_word = (uint32_t)rtm::d2u(q4.y);
+                }
                 double t;
-                if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
+                if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0, mat_word);
                 T_NEXT();
             }
         } else if (best == OP_RECT) {
             cnt.prim(RT_KIND_RECT);
-            const rt_rect &q = s.rects[RT_REF_INDEX(L.top)];
+            const f64x2 *qp = reinterpret_cast<const f64x2 *>(s.rects + RT_REF_INDEX(L.top));      // rt_rect, 48 B: a0 a1 | b0 b1 | k, axis+mat
+            f64x2 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+            t_pin(q0); t_pin(q1); t_pin(q2);
+            const uint64_t am = rtm::d2u(q2.y);
             double t;
-            if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, L.cur, L.t_lo, t_hi(L), t)) t_accept(L, t, 0);
+            if (rect_t((uint32_t)am, q0.x, q0.y, q1.x, q1.y, q2.x, L.cur, L.t_lo, t_hi(L), t)) t_accept(L, t, 0, (uint32_t)(am >> 32));
             T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_BOX) {
             cnt.prim(RT_KIND_BOX);
+            const uint32_t bidx = RT_REF_INDEX(L.top);
+            const f64x2_a8 *bp = reinterpret_cast<const f64x2_a8 *>(s.boxes + bidx);                // rt_box, 56 B: p0, p1, mat
+            f64x2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+            uint32_t mat_word = s.boxes[bidx].mat;
+            t_pin(b0); t_pin(b1); t_pin(b2); t_pin(mat_word);
             double t;
             uint32_t face = 0;
-            if (box_t(s.boxes[RT_REF_INDEX(L.top)], L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face);
+            if (t_box(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face, mat_word);
             T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83
-            if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM && RT_REF_KIND(s.media[RT_REF_INDEX(L.top)].boundary) == RT_KIND_SPHERE) {
+            // (the medium's record — boundary sphere inline — in one fetch: MediumDev, pt_device.h)
+            f64x2 m0{0.0, 0.0}, m1{0.0, 0.0}, m2{0.0, 0.0};
+            u32x4 m3{0u, 0u, 0u, 0u};
+            const bool is_leaf = RT_REF_KIND(L.top) == RT_KIND_MEDIUM;
+            if (is_leaf) {
+                const f64x2 *mp = reinterpret_cast<const f64x2 *>(s.media_dev + RT_REF_INDEX(L.top));
+                m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+                m3 = reinterpret_cast<const u32x4 *>(mp)[3];
+            }
+            t_pin(m0); t_pin(m1); t_pin(m2); t_pin(m3);
+            if (is_leaf && m3.x != 0u) {
                 // ConstantMedium::hit with a Sphere boundary, constantmedium.rs:49-83 in one go: the two
                 // boundary queries are Sphere::hit (sphere.rs:39-58) on the same sphere with different t_min.
-                const rt_medium &m = s.media[RT_REF_INDEX(L.top)];
-                const rt_sphere &q = s.spheres[RT_REF_INDEX(m.boundary)];
-                const Vec3 center = ld3(q.center);
+                struct { double neg_inv_density; } m{m2.x};
+                struct { double radius; } q{m1.y};
+                const Vec3 center(m0.x, m0.y, m1.x);
+                const uint32_t mat_word = (uint32_t)(rtm::d2u(m2.y) >> 32);
                 cnt.prim(RT_KIND_MEDIUM);
                 cnt.prim(RT_KIND_SPHERE);
                 double t1, t2 = 0.0;
@@ -761,7 +836,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                         double distance_inside_boundary = (t2 - t1) * ray_length;
                         double rnd = L.rng.gen_f64();
                         double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
-                        if (!(hit_distance > distance_inside_boundary)) t_accept(L, t1 + hit_distance / ray_length, 0);   // (L.top is the medium)
+                        if (!(hit_distance > distance_inside_boundary)) t_accept(L, t1 + hit_distance / ray_length, 0, mat_word);   // (L.top is the medium)
                     }
                 }
                 T_NEXT();
@@ -773,7 +848,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 double t2 = L.sub_closest;
                 L.med_ref = 0; L.t_lo = t_min;                        // back in the main query
                 if (both) {
-                    const rt_medium &m = s.media[RT_REF_INDEX(mref)];
+                    const MediumDev &m = s.media_dev[RT_REF_INDEX(mref)];
                     double t1 = rtm::fmax_(L.med_t1, t_min);
                     t2 = rtm::fmin_(t2, L.closest);
                     if (!(t1 >= t2)) {
@@ -784,7 +859,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                         double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));
                         if (!(hit_distance > distance_inside_boundary)) {
                             L.top = mref;                             // the medium itself is the winning leaf
-                            t_accept(L, t1 + hit_distance / ray_length, 0);
+                            t_accept(L, t1 + hit_distance / ray_length, 0, m.mat);
                         }
                     }
                 }
@@ -794,15 +869,45 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
             cnt.prim(kind);
             double t;
-            bool h = kind == RT_KIND_TRIANGLE ? triangle_t(s.triangles[idx], L.cur, L.t_lo, t_hi(L), t)
-                                              : ring_t(s.rings[idx], L.cur, L.t_lo, t_hi(L), t);
-            if (h) t_accept(L, t, 0);
+            bool h;
+            uint32_t mat_word;
+            if (kind == RT_KIND_TRIANGLE) {                           // rt_triangle, 80 B: a, b, c, mat
+                const f64x2 *qp = reinterpret_cast<const f64x2 *>(s.triangles + idx);
+                f64x2 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3], q4 = qp[4];
+                t_pin(q0); t_pin(q1); t_pin(q2); t_pin(q3); t_pin(q4);
+                rt_triangle tr;
+                tr.a[0] = q0.x; tr.a[1] = q0.y; tr.a[2] = q1.x; tr.b[0] = q1.y; tr.b[1] = q2.x; tr.b[2] = q2.y;
+                tr.c[0] = q3.x; tr.c[1] = q3.y; tr.c[2] = q4.x;
+                mat_word = (uint32_t)rtm::d2u(q4.y);
+                h = triangle_t(tr, L.cur, L.t_lo, t_hi(L), t);
+            } else {
+                mat_word = s.rings[idx].mat;
+                h = ring_t(s.rings[idx], L.cur, L.t_lo, t_hi(L), t);
+            }
+            if (h) t_accept(L, t, 0, mat_word);
             T_NEXT();
         } else if ((FEAT & kFeatMovers) && best == OP_CTX) {                                  // movers in / out, HittableList expansion
+            // 1/d of the ray changes only where d does: RotateY (x and z). Translate and Zoom leave the direction alone
+            // (hittable/mod.rs:165-167,321-323), so entering or leaving them keeps inv and a_len — the same values the
+            // three divisions would give again.
             if (L.top == REF_POPCTX) {
                 L.ctx.n--;
-                Ray wr = pv.load_ray(L.slot);
-                t_set_cur(L, ray_at_level(s, L.ctx, L.ctx.n, XRay{wr.orig, wr.dir}), boxes_plain);
+                const uint32_t left_kind = RT_REF_KIND(L.ctx.at(L.ctx.n));           // the mover being left
+                // the world ray from this lane's LDS column (written at refill), then back down to the enclosing frame
+                XRay world;
+                if (kStash) {
+                    world = XRay{Vec3(wray[0 * kBlock], wray[1 * kBlock], wray[2 * kBlock]), Vec3(wray[3 * kBlock], wray[4 * kBlock], wray[5 * kBlock])};
+                } else {
+                    Ray wr = pv.load_ray(L.slot);
+                    world = XRay{wr.orig, wr.dir};
+                }
+                L.cur = ray_at_level(s, L.ctx, L.ctx.n, world);
+                if (left_kind == RT_KIND_ROTATE_Y) {
+                    if (L.stash_level == L.ctx.n) { L.inv.x = L.stash_ix; L.inv.z = L.stash_iz; L.stash_level = 0xFFFFFFFFu; }
+                    else { L.inv.x = 1.0 / L.cur.d.x; L.inv.z = 1.0 / L.cur.d.z; }
+                    L.a_len = L.cur.d.length_sqr();
+                }
+                t_flags(L, boxes_plain);
                 T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -812,10 +917,27 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                     for (uint32_t i = l.count; i > 0; i--) st.push(L, s.list_items[l.first + i - 1]);
                     T_NEXT();
                 } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
+                    const u32x4 *xp = reinterpret_cast<const u32x4 *>(s.xforms + idx);              // rt_xform, 32 B: kind, child, p[3]
+                    u32x4 x0 = xp[0];
+                    f64x2 x1 = reinterpret_cast<const f64x2 *>(xp)[1];
+                    t_pin(x0); t_pin(x1);
+                    const double p0 = rtm::u2d(((uint64_t)x0.w << 32) | x0.z), p1 = x1.x, p2 = x1.y;
+                    if (kind == RT_KIND_TRANSLATE) {                  // Translate::hit, mod.rs:165-167
+                        L.cur.o = L.cur.o - Vec3(p0, p1, p2);
+                    } else if (kind == RT_KIND_ROTATE_Y) {            // RotateY::hit, mod.rs:235-247 (p0 = sin, p1 = cos)
+                        const double ox = p1 * L.cur.o.x - p0 * L.cur.o.z, oz = p0 * L.cur.o.x + p1 * L.cur.o.z;
+                        const double dx = p1 * L.cur.d.x - p0 * L.cur.d.z, dz = p0 * L.cur.d.x + p1 * L.cur.d.z;
+                        L.cur.o.x = ox; L.cur.o.z = oz; L.cur.d.x = dx; L.cur.d.z = dz;
+                        L.stash_ix = L.inv.x; L.stash_iz = L.inv.z; L.stash_level = L.ctx.n;
+                        L.inv.x = 1.0 / dx; L.inv.z = 1.0 / dz;
+                        L.a_len = L.cur.d.length_sqr();
+                    } else {                                          // Zoom::hit, mod.rs:321-323: the origin only
+                        L.cur.o = L.cur.o / p0;
+                    }
+                    t_flags(L, boxes_plain);
                     L.ctx.push(L.top);
-                    t_set_cur(L, xform_ray(s, L.top, L.cur), boxes_plain);
                     st.push(L, REF_POPCTX);
-                    L.top = s.xforms[idx].child;
+                    L.top = x0.y;
                     T_SETTLE();
                 } else {
                     T_NEXT();
@@ -831,7 +953,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 const uint32_t steps16 = (L.steps > 0xFFFFu ? 0xFFFFu : L.steps) << 16;
                 if (found) {
                     pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain);
-                    kind = leaf_material_word(s, L.win_leaf) >> kMatKindShift;
+                    kind = L.win_mat >> kMatKindShift;                // (the word came with the winning primitive's record)
                 }
                 pool.kind[slot] = (uint8_t)kind;
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
@@ -875,6 +997,11 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
+                if (FEAT & kFeatMovers) L.stash_level = 0xFFFFFFFFu;
+                if (kStash) {                                         // what leaving a mover goes back to (OP_CTX)
+                    wray[0 * kBlock] = wr.orig.x; wray[1 * kBlock] = wr.orig.y; wray[2 * kBlock] = wr.orig.z;
+                    wray[3 * kBlock] = wr.dir.x; wray[4 * kBlock] = wr.dir.y; wray[5 * kBlock] = wr.dir.z;
+                }
                 L.closest = rtm::F64_MAX;
                 L.steps = 0;
                 L.t_lo = t_min; L.med_ref = 0;

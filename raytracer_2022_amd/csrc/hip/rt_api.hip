@@ -571,6 +571,26 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.triangles = packed(desc->triangles, desc->n_triangles);
             s.rings = packed(desc->rings, desc->n_rings);
             s.media = packed(desc->media, desc->n_media);
+            {
+                std::vector<MediumDev> md(desc->n_media);
+                uint32_t n_sph = 0;
+                for (uint32_t i = 0; i < desc->n_media; i++) {
+                    const rt_medium &m = desc->media[i];
+                    MediumDev &q = md[i];
+                    std::memset(&q, 0, sizeof q);
+                    q.neg_inv_density = m.neg_inv_density;
+                    q.boundary = m.boundary;
+                    q.mat = m.mat | ((uint32_t)SK_ISOTROPIC << kMatKindShift);
+                    if (RT_REF_KIND(m.boundary) == RT_KIND_SPHERE && !(m.boundary & RT_REF_FLIP)) {
+                        const rt_sphere &sp = desc->spheres[RT_REF_INDEX(m.boundary)];
+                        q.center[0] = sp.center[0]; q.center[1] = sp.center[1]; q.center[2] = sp.center[2]; q.radius = sp.radius;
+                        q.sphere_boundary = 1;
+                        n_sph++;
+                    }
+                }
+                s.media_dev = upload(md.data(), md.size(), sc->owned);
+                s.media_mode = n_sph == 0 ? 0u : n_sph == desc->n_media ? 1u : 2u;
+            }
             s.xforms = upload(desc->xforms, desc->n_xforms, sc->owned);
             s.lists = upload(desc->lists, desc->n_lists, sc->owned);
             s.list_items = upload(desc->list_items, desc->n_list_items, sc->owned);
