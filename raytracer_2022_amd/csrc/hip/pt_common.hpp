@@ -538,64 +538,100 @@ RT_DEV Vec3 random_cosine_direction(Rng &rng) {
 
 // ---- light list: HittableList::pdf_value / random over Sphere and rect lights -------
 // (sphere.rs:75-90, aarect.rs:74-93,157-176,240-259, mod.rs:62-67,121-132)
+// One entry of `lights` with its primitive's numbers beside the ref, so that a kernel may keep the list in LDS.
+struct LightRec {
+    double v[5];           // Sphere: center x y z, radius, -;  rect: a0, a1, b0, b1, k
+    uint32_t axis;         // rect axis
+    uint32_t ref;          // the entry of `lights` (kind, FlipFace bit)
+};
+RT_DEV LightRec fetch_light(const SceneDev &s, uint32_t li) {
+    LightRec q;
+    q.ref = s.lights[li];
+    q.axis = 0;
+    q.v[0] = q.v[1] = q.v[2] = q.v[3] = q.v[4] = 0.0;
+    const uint32_t kind = RT_REF_KIND(q.ref), idx = RT_REF_INDEX(q.ref);
+    if (kind == RT_KIND_SPHERE) {
+        const rt_sphere &p = s.spheres[idx];
+        q.v[0] = p.center[0]; q.v[1] = p.center[1]; q.v[2] = p.center[2]; q.v[3] = p.radius;
+    } else if (kind == RT_KIND_RECT) {
+        const rt_rect &p = s.rects[idx];
+        q.v[0] = p.a0; q.v[1] = p.a1; q.v[2] = p.b0; q.v[3] = p.b1; q.v[4] = p.k; q.axis = p.axis;
+    }
+    return q;
+}
+// One light's pdf_value(o, v): Sphere (sphere.rs:75-83), X?Rect (aarect.rs:74-83 and twins); anything else — a
+// FlipFace'd light included — answers the trait default 0 (mod.rs:62-64).
 template <bool STATS>
-RT_DEV double lights_pdf_value(const SceneDev &s, Vec3 o, Vec3 v, Counters<STATS> &cnt) {
-    double sum = 0.0;
-    for (uint32_t li = 0; li < s.n_lights; li++) {
-        uint32_t ref = s.lights[li];
-        uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
-        double val = 0.0;
-        XRay r{o, v};
-        if (!(ref & RT_REF_FLIP)) {
-            if (kind == RT_KIND_SPHERE) {
-                const rt_sphere &q = s.spheres[idx];
-                cnt.light_pdf();
-                double t;
-                if (sphere_t(ld3(q.center), q.radius, r, v.length_sqr(), 0.001, rtm::INF, t)) {
-                    double cos_max = rtm::sqrt_(1.0 - q.radius * q.radius / (ld3(q.center) - o).length_sqr());
-                    double solid_angle = 2.0 * rtm::PI * (1.0 - cos_max);
-                    val = 1.0 / solid_angle;
-                }
-            } else if (kind == RT_KIND_RECT) {
-                const rt_rect &q = s.rects[idx];
-                cnt.light_pdf();
-                double t;
-                if (rect_t(q.axis, q.a0, q.a1, q.b0, q.b1, q.k, r, 0.001, rtm::INF, t)) {
-                    HitRec rec;
-                    RectP rp{q.axis, q.a0, q.a1, q.b0, q.b1, q.k};
-                    rect_record(rp, q.mat, r, t, rec);
-                    double area = (q.a1 - q.a0) * (q.b1 - q.b0);
-                    double dis_sqr = rec.t * rec.t * v.length_sqr();
-                    double cosv = rtm::fabs_(rtm::dot(v, rec.normal) / v.length());
-                    val = dis_sqr / (cosv * area);
-                }
+RT_DEV double light_pdf_value(const LightRec &q, Vec3 o, Vec3 v, Counters<STATS> &cnt) {
+    const uint32_t kind = RT_REF_KIND(q.ref);
+    double val = 0.0;
+    XRay r{o, v};
+    if (!(q.ref & RT_REF_FLIP)) {
+        if (kind == RT_KIND_SPHERE) {
+            const Vec3 center(q.v[0], q.v[1], q.v[2]);
+            const double radius = q.v[3];
+            cnt.light_pdf();
+            double t;
+            if (sphere_t(center, radius, r, v.length_sqr(), 0.001, rtm::INF, t)) {
+                double cos_max = rtm::sqrt_(1.0 - radius * radius / (center - o).length_sqr());
+                double solid_angle = 2.0 * rtm::PI * (1.0 - cos_max);
+                val = 1.0 / solid_angle;
+            }
+        } else if (kind == RT_KIND_RECT) {
+            cnt.light_pdf();
+            double t;
+            if (rect_t(q.axis, q.v[0], q.v[1], q.v[2], q.v[3], q.v[4], r, 0.001, rtm::INF, t)) {
+                HitRec rec;
+                RectP rp{q.axis, q.v[0], q.v[1], q.v[2], q.v[3], q.v[4]};
+                rect_record(rp, 0u, r, t, rec);
+                double area = (q.v[1] - q.v[0]) * (q.v[3] - q.v[2]);
+                double dis_sqr = rec.t * rec.t * v.length_sqr();
+                double cosv = rtm::fabs_(rtm::dot(v, rec.normal) / v.length());
+                val = dis_sqr / (cosv * area);
             }
         }
-        sum += val;
     }
-    return sum / (double)s.n_lights;
+    return val;
 }
-RT_DEV Vec3 lights_random(const SceneDev &s, Vec3 o, Rng &rng) {
-    uint64_t target = rng.gen_index(s.n_lights);
-    uint32_t ref = s.lights[target];
-    uint32_t kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
-    if (!(ref & RT_REF_FLIP)) {
+// One light's random(o): Sphere (sphere.rs:85-90), X?Rect (aarect.rs:85-93 and twins); else (1, 0, 0) (mod.rs:65-67).
+RT_DEV Vec3 light_random(const LightRec &q, Vec3 o, Rng &rng) {
+    const uint32_t kind = RT_REF_KIND(q.ref);
+    if (!(q.ref & RT_REF_FLIP)) {
         if (kind == RT_KIND_SPHERE) {
-            const rt_sphere &q = s.spheres[idx];
-            Vec3 direction = ld3(q.center) - o;
+            const Vec3 center(q.v[0], q.v[1], q.v[2]);
+            Vec3 direction = center - o;
             double dis_sqr = direction.length_sqr();
             rtm::Onb uvw = rtm::onb_from_w(direction);
-            return uvw.local_vec(random_to_sphere(rng, q.radius, dis_sqr));
+            return uvw.local_vec(random_to_sphere(rng, q.v[3], dis_sqr));
         }
         if (kind == RT_KIND_RECT) {
-            const rt_rect &q = s.rects[idx];
-            double a = rng.gen_range(q.a0, q.a1);
-            double b = rng.gen_range(q.b0, q.b1);
-            Vec3 random_point = q.axis == RT_RECT_XY ? Vec3(a, b, q.k) : q.axis == RT_RECT_XZ ? Vec3(a, q.k, b) : Vec3(q.k, a, b);
+            double a = rng.gen_range(q.v[0], q.v[1]);
+            double b = rng.gen_range(q.v[2], q.v[3]);
+            const double k = q.v[4];
+            Vec3 random_point = q.axis == RT_RECT_XY ? Vec3(a, b, k) : q.axis == RT_RECT_XZ ? Vec3(a, k, b) : Vec3(k, a, b);
             return random_point - o;
         }
     }
     return Vec3(1.0, 0.0, 0.0);
+}
+// HittableList::pdf_value / random (mod.rs:121-132) over a list reached through `fetch(i)`.
+template <bool STATS, class Fetch>
+RT_DEV double lights_pdf_value_of(uint32_t n_lights, Fetch fetch, Vec3 o, Vec3 v, Counters<STATS> &cnt) {
+    double sum = 0.0;
+    for (uint32_t li = 0; li < n_lights; li++) sum += light_pdf_value<STATS>(fetch(li), o, v, cnt);
+    return sum / (double)n_lights;
+}
+template <class Fetch>
+RT_DEV Vec3 lights_random_of(uint32_t n_lights, Fetch fetch, Vec3 o, Rng &rng) {
+    uint64_t target = rng.gen_index(n_lights);
+    return light_random(fetch((uint32_t)target), o, rng);
+}
+template <bool STATS>
+RT_DEV double lights_pdf_value(const SceneDev &s, Vec3 o, Vec3 v, Counters<STATS> &cnt) {
+    return lights_pdf_value_of<STATS>(s.n_lights, [&](uint32_t li) { return fetch_light(s, li); }, o, v, cnt);
+}
+RT_DEV Vec3 lights_random(const SceneDev &s, Vec3 o, Rng &rng) {
+    return lights_random_of(s.n_lights, [&](uint32_t li) { return fetch_light(s, li); }, o, rng);
 }
 
 RT_DEV double reflectance(double cosv, double ref_idx) {            // material/mod.rs:112-116

@@ -23,6 +23,17 @@ struct MediumDev {
     uint32_t _pad[3];
 };
 
+// A material as the shading kernel wants it: one 80-byte record = one fetch, with the top-level record of its texture
+// inline (kind, children / table ids, scale, colour) — a SolidColor albedo then needs no second, dependent fetch.
+struct MaterialDev {
+    uint32_t tex, tex_kind;            // rt_material::tex and that texture's kind
+    double albedo[3];                  // Metal
+    double param;                      // Metal fuzz / Dielectric ir
+    double tex_color[3];               // rt_texture::color
+    double tex_scale;                  // rt_texture::scale
+    uint32_t tex_a, tex_b;             // rt_texture::a, b
+};
+
 // Pointers into HBM, one pool per kind (layouts = include/rt2022.h).
 struct SceneDev {
     const rt_bvh_node *nodes;
@@ -44,6 +55,7 @@ struct SceneDev {
     const rt_perlin *perlins;
     uint32_t root;
     uint32_t n_lights;
+    const MaterialDev *materials_dev;  // [n_materials], shading kernel's view of `materials` + `textures`
     const MediumDev *media_dev;        // [n_media], traversal kernel's view of `media`
     uint32_t media_mode;               // 0: no medium has a plain-sphere boundary, 1: all have, 2: mixed (look at the record)
 };

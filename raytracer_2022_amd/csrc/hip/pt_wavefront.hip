@@ -46,6 +46,16 @@ constexpr int S = kSlotsPerBlock;
 constexpr uint32_t kListBins = 16 * 8;     // list order: 16 classes of expected length x 8 direction octants
 constexpr uint32_t kChunk = RT2022_CHUNK;           // list entries a wave claims at a time
 
+// Records are fetched whole and at once — a few 16-byte loads issued back to back and waited for together — never
+// field by field as the arithmetic gets to them: left to itself the compiler sinks each field's load into the branch
+// that uses it, and an arm like Boxes::hit then waits for memory six to ten times in a row (seen in the ISA). The empty
+// asm pins the value: the load cannot move below it, and everything pinned together shares one wait.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // (records whose size is 8 mod 16)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
+
 struct PoolView {
     const WfPool &p;
     // Ray + RNG state: one 64-byte line per slot.
@@ -67,22 +77,23 @@ struct PoolView {
     // Winner of the traversal: one 32-byte record per slot.
     // meta = box face | movers << 4 | node steps of the traversal << 16 (the shade pass orders the next
     // trace pass by them); a miss stores nothing (its path ends).
-    RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch) const {
-        uint4 *q = reinterpret_cast<uint4 *>(p.hit + (uint64_t)slot * 8);
+    // Second half = the movers enclosing the leaf; its last word holds the leaf's material word instead whenever the
+    // chain leaves it free (fewer than four movers): the shade pass then needs no look at the primitive for it.
+    RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch, uint32_t mat_word) const {
+        u32x4 *q = reinterpret_cast<u32x4 *>(p.hit + (uint64_t)slot * 8);
         uint64_t tb = rtm::d2u(t);
-        q[0] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta);
-        if (ch.n > 0) q[1] = make_uint4(ch.c0, ch.c1, ch.c2, ch.c3);
+        q[0] = (u32x4){(uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta};
+        q[1] = (u32x4){ch.c0, ch.c1, ch.c2, ch.n >= 4u ? ch.c3 : mat_word};
     }
-    RT_DEV void load_hit(uint32_t slot, Winner &w, uint32_t &steps) const {
-        const uint4 *q = reinterpret_cast<const uint4 *>(p.hit + (uint64_t)slot * 8);
-        uint4 a = q[0];
+    RT_DEV static void decode_hit(u32x4 a, u32x4 b, Winner &w, uint32_t &steps, uint32_t &mat_word, bool &have_mat) {
         w.t = rtm::u2d(((uint64_t)a.y << 32) | a.x);
         w.leaf = a.z;
         w.face = a.w & 0xFu;
         w.chain.n = (a.w >> 4) & 0xFu;
         steps = a.w >> 16;
-        w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
-        if (w.chain.n > 0) { uint4 b = q[1]; w.chain.c0 = b.x; w.chain.c1 = b.y; w.chain.c2 = b.z; w.chain.c3 = b.w; }
+        have_mat = w.chain.n < 4u;
+        mat_word = b.w;
+        w.chain.c0 = b.x; w.chain.c1 = b.y; w.chain.c2 = b.z; w.chain.c3 = have_mat ? 0u : b.w;
     }
 };
 
@@ -151,7 +162,99 @@ RT_DEV uint32_t leaf_material_word(const SceneDev &s, uint32_t leaf) {
     }
 }
 
-RT_DEV uint32_t leaf_material(const SceneDev &s, uint32_t leaf) { return leaf_material_word(s, leaf) & kMatIndexMask; }
+
+// The winning primitive's record as the shade pass fetches it: a fixed 80 bytes from the record's address, whatever
+// the kind (the longest records — Triangle, MovingSphere — are 80 bytes; shorter ones run on into their neighbour or
+// into the pool's zeroed slack, rt_scene_create) — one address computation, five loads, no branch.
+struct PrimRegs { f64x2 r0, r1, r2, r3, r4; };
+RT_DEV const f64x2_a8 *prim_address(const SceneDev &s, uint32_t leaf) {
+    const uint32_t kind = RT_REF_KIND(leaf), idx = RT_REF_INDEX(leaf);
+    const char *base = reinterpret_cast<const char *>(s.media);
+    uint32_t stride = (uint32_t)sizeof(rt_medium);
+    if (kind == RT_KIND_SPHERE) { base = reinterpret_cast<const char *>(s.spheres); stride = (uint32_t)sizeof(rt_sphere); }
+    else if (kind == RT_KIND_MOVING_SPHERE) { base = reinterpret_cast<const char *>(s.moving_spheres); stride = (uint32_t)sizeof(rt_moving_sphere); }
+    else if (kind == RT_KIND_RECT) { base = reinterpret_cast<const char *>(s.rects); stride = (uint32_t)sizeof(rt_rect); }
+    else if (kind == RT_KIND_BOX) { base = reinterpret_cast<const char *>(s.boxes); stride = (uint32_t)sizeof(rt_box); }
+    else if (kind == RT_KIND_TRIANGLE) { base = reinterpret_cast<const char *>(s.triangles); stride = (uint32_t)sizeof(rt_triangle); }
+    else if (kind == RT_KIND_RING) { base = reinterpret_cast<const char *>(s.rings); stride = (uint32_t)sizeof(rt_ring); }
+    return reinterpret_cast<const f64x2_a8 *>(base + (uint64_t)idx * stride);
+}
+// winner_record (pt_common.hpp) fed from registers: the HitRecord of the winning candidate, rebuilt from (leaf, t) in
+// the leaf's own frame (sphere.rs:59-65,158-164, aarect.rs:51-71, boxes.rs:24-66, triangle.rs:54-76, ring.rs:49-52,
+// constantmedium.rs:66-74) and then carried out through its movers.
+RT_DEV void winner_record_regs(const SceneDev &s, const Ray &wr, const Winner &w, const PrimRegs &q, HitRec &rec, bool want_uv) {
+    const XRay world{wr.orig, wr.dir};
+    XRay r = ray_at_level(s, w.chain, w.chain.n, world);
+    const uint32_t kind = RT_REF_KIND(w.leaf);
+    const double t = w.t;
+    rec.mat = 0;
+    switch (kind) {
+        case RT_KIND_SPHERE: case RT_KIND_MOVING_SPHERE: {
+            Vec3 center; double radius;
+            if (kind == RT_KIND_SPHERE) { center = Vec3(q.r0.x, q.r0.y, q.r1.x); radius = q.r1.y; }
+            else {
+                const Vec3 c0(q.r0.x, q.r0.y, q.r1.x), c1(q.r1.y, q.r2.x, q.r2.y);
+                center = c0 + (c1 - c0) * ((wr.tm - q.r3.x) / (q.r3.y - q.r3.x));
+                radius = q.r4.x;
+            }
+            Vec3 at = r.o + r.d * t;
+            Vec3 outward_normal = (at - center) / radius;
+            rec.u = 0.0; rec.v = 0.0;
+            if (want_uv) sphere_uv(outward_normal, rec.u, rec.v);
+            rec.p = at; rec.t = t;
+            rec.set_face_normal(r.d, outward_normal);
+            break;
+        }
+        case RT_KIND_RECT: {
+            RectP rp{(uint32_t)rtm::d2u(q.r2.y), q.r0.x, q.r0.y, q.r1.x, q.r1.y, q.r2.x};
+            rect_record(rp, 0u, r, t, rec);
+            break;
+        }
+        case RT_KIND_BOX: {
+            const double p0x = q.r0.x, p0y = q.r0.y, p0z = q.r1.x, p1x = q.r1.y, p1y = q.r2.x, p1z = q.r2.y;
+            const uint32_t i = w.face;
+            RectP rp;                                                // boxes.rs:24-66
+            if (i < 2) rp = RectP{RT_RECT_XY, p0x, p1x, p0y, p1y, i == 0 ? p1z : p0z};
+            else if (i < 4) rp = RectP{RT_RECT_XZ, p0x, p1x, p0z, p1z, i == 2 ? p1y : p0y};
+            else rp = RectP{RT_RECT_YZ, p0y, p1y, p0z, p1z, i == 4 ? p1x : p0x};
+            rect_record(rp, 0u, r, t, rec);
+            break;
+        }
+        case RT_KIND_TRIANGLE: {
+            const Vec3 a(q.r0.x, q.r0.y, q.r1.x), b(q.r1.y, q.r2.x, q.r2.y), c(q.r3.x, q.r3.y, q.r4.x);
+            Vec3 n = rtm::to_unit(rtm::cross(b - a, c - a));
+            Vec3 p = r.o + r.d * t;
+            double a1 = a.x - b.x, b1 = a.x - c.x, c1 = a.x - p.x;
+            double a2 = a.y - b.y, b2 = a.y - c.y, c2 = a.y - p.y;
+            rec.u = (c1 * b2 - b1 * c2) / (a1 * b2 - b1 * a2);
+            rec.v = (a1 * c2 - a2 * c1) / (a1 * b2 - b1 * a2);
+            rec.p = p; rec.t = t;
+            rec.set_face_normal(r.d, n);
+            break;
+        }
+        case RT_KIND_RING: {
+            rec.p = r.o + r.d * t; rec.t = t; rec.u = 0.0; rec.v = 0.0;
+            rec.set_face_normal(r.d, Vec3(0.0, 1.0, 0.0));
+            break;
+        }
+        default: {
+            rec.p = r.o + r.d * t; rec.normal = Vec3(1.0, 0.0, 0.0); rec.t = t; rec.u = 0.0; rec.v = 0.0;
+            rec.front_face = true;
+            break;
+        }
+    }
+    if (w.leaf & RT_REF_FLIP) rec.front_face = !rec.front_face;
+    for (uint32_t lvl = w.chain.n; lvl > 0; lvl--) {
+        XRay moved = ray_at_level(s, w.chain, lvl, world);
+        xform_record(s, w.chain.at(lvl - 1), moved, rec);
+    }
+}
+// Texture::value of a material's texture whose top-level record came with the material (MaterialDev): a SolidColor
+// answers from registers; everything else goes the general way.
+RT_DEV Vec3 texture_value_top(const SceneDev &s, uint32_t tex, uint32_t tex_kind, Vec3 color, double u, double v, Vec3 p) {
+    if (tex_kind == RT_TEX_SOLID) return color;
+    return texture_value(s, tex, u, v, p);
+}
 
 } // namespace
 
@@ -174,6 +277,12 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
 
+    // The light list with its primitives' numbers, in LDS when it is short (it is one or two entries in every scene of
+    // the reference): MixturePdf's two visits per bounce (generate + value, pdf.rs:94-104) then cost no memory round trip.
+    constexpr uint32_t kLdsLights = 8;
+    __shared__ LightRec lights_lds[kLdsLights];
+    if (tid < kLdsLights && tid < s.n_lights) lights_lds[tid] = fetch_light(s, tid);
+    auto light_at = [&](uint32_t li) { return li < kLdsLights ? lights_lds[li] : fetch_light(s, li); };
     if (tid < SK_COUNT) hist[tid] = 0;
     __syncthreads();
     // Counting sort of the block's slots by kind (idle slots and nothing else are dropped).
@@ -225,15 +334,34 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         Winner w;
         w.t = 0.0; w.leaf = 0; w.face = 0; w.chain.n = 0; w.chain.c0 = w.chain.c1 = w.chain.c2 = w.chain.c3 = 0;
         uint32_t steps = 0;          // node steps of the ray that has just been traced
+        uint32_t mat_word = 0;
+        PrimRegs prim{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+        f64x2 md0{0.0, 0.0}, md1{0.0, 0.0}, md2{0.0, 0.0}, md3{0.0, 0.0}, md4{0.0, 0.0};      // MaterialDev
         if (on) {
             stt = load_state(pool, slot);
             if (kind > SK_MISS) {                                 // (a miss ends its path and a fresh slot has none: neither needs the ray or the winner)
                 uint64_t rs;
                 r = pv.load_ray(slot, rs);
                 rng = Rng(rs);
-                pv.load_hit(slot, w, steps);
+                const u32x4 *hq = reinterpret_cast<const u32x4 *>(pool.hit + (uint64_t)slot * 8);
+                u32x4 ha = hq[0], hb = hq[1];
+                t_pin(ha); t_pin(hb);
+                bool have_mat;
+                PoolView::decode_hit(ha, hb, w, steps, mat_word, have_mat);
+                if (!have_mat) mat_word = leaf_material_word(s, w.leaf);      // (four movers deep: the chain needed the word's place)
+                // second round trip, everything at once: the winning primitive's record and its material's
+                const f64x2_a8 *pp = prim_address(s, w.leaf);
+                const f64x2 *mp = reinterpret_cast<const f64x2 *>(s.materials_dev + (mat_word & kMatIndexMask));
+                prim.r0 = pp[0]; prim.r1 = pp[1]; prim.r2 = pp[2]; prim.r3 = pp[3]; prim.r4 = pp[4];
+                md0 = mp[0]; md1 = mp[1]; md2 = mp[2]; md3 = mp[3]; md4 = mp[4];
+                t_pin(prim.r0); t_pin(prim.r1); t_pin(prim.r2); t_pin(prim.r3); t_pin(prim.r4);
+                t_pin(md0); t_pin(md1); t_pin(md2); t_pin(md3); t_pin(md4);
             }
         }
+        // MaterialDev: tex, tex_kind | albedo | param | tex_color | tex_scale | tex_a, tex_b
+        const uint32_t m_tex = (uint32_t)rtm::d2u(md0.x), m_tex_kind = (uint32_t)(rtm::d2u(md0.x) >> 32);
+        const Vec3 m_albedo(md0.y, md1.x, md1.y), m_tex_color(md2.y, md3.x, md3.y);
+        const double m_param = md2.x;
         // (top bit of the stored depth: some record of the path's tape is not "finite weight, pdf neither 0 nor NaN")
         uint32_t depth = stt.depth & 0x7FFFFFFFu;
         uint32_t tainted = stt.depth >> 31;
@@ -249,19 +377,17 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 ended = true;
             } else {
                 // (u, v) only matter to image textures (and to a checker that may select one).
-                const rt_material &mat = s.materials[leaf_material(s, w.leaf)];
                 bool want_uv = false;
                 const bool lambertian = kind >= SK_LAMB_SOLID && kind <= SK_LAMB_IMAGE;
                 if (lambertian) {                                     // (the slot kind says which texture it is)
                     want_uv = kind == SK_LAMB_IMAGE || kind == SK_LAMB_CHECKER;
                 } else if (kind == SK_LIGHT || kind == SK_ISOTROPIC) {
-                    uint32_t tk = s.textures[mat.tex].kind;
-                    want_uv = tk == RT_TEX_IMAGE || tk == RT_TEX_CHECKER;
+                    want_uv = m_tex_kind == RT_TEX_IMAGE || m_tex_kind == RT_TEX_CHECKER;
                 }
                 HitRec rec;
-                winner_record(s, r, w, rec, want_uv);
+                winner_record_regs(s, r, w, prim, rec, want_uv);
                 if (kind == SK_LIGHT) {                               // emitted; scatter = None (material/mod.rs:16-18,174-180)
-                    Lterm = rec.front_face ? texture_value(s, mat.tex, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);
+                    Lterm = rec.front_face ? texture_value_top(s, m_tex, m_tex_kind, m_tex_color, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);
                     ended = true;
                 } else {
                     Vec3 wgt;
@@ -269,7 +395,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     Vec3 dir;
                     double tm = r.tm;
                     if (lambertian) {                                 // material/mod.rs:51-65 + main.rs:263-271
-                        Vec3 att = texture_value(s, mat.tex, rec.u, rec.v, rec.p);
+                        Vec3 att = texture_value_top(s, m_tex, m_tex_kind, m_tex_color, rec.u, rec.v, rec.p);
                         rtm::Onb uvw = rtm::onb_from_w(rec.normal);
                         double cosv;
                         if (s.n_lights == 0) {                        // cosine-only mode
@@ -277,9 +403,9 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                             cosv = rtm::dot(rtm::to_unit(dir), uvw.w);
                             p = cosv <= 0.0 ? 0.0 : cosv / rtm::PI;
                         } else {                                      // MixturePdf(lights, cos), pdf.rs:94-104
-                            if (rng.gen_range(0.0, 1.0) < 0.5) dir = lights_random(s, rec.p, rng);
+                            if (rng.gen_range(0.0, 1.0) < 0.5) dir = lights_random_of(s.n_lights, light_at, rec.p, rng);
                             else dir = uvw.local_vec(random_cosine_direction(rng));
-                            double lp = lights_pdf_value<STATS>(s, rec.p, dir, cnt);
+                            double lp = lights_pdf_value_of<STATS>(s.n_lights, light_at, rec.p, dir, cnt);
                             cosv = rtm::dot(rtm::to_unit(dir), uvw.w);
                             double cp = cosv <= 0.0 ? 0.0 : cosv / rtm::PI;
                             p = 0.5 * lp + 0.5 * cp;
@@ -289,11 +415,11 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                         wgt = att * spdf;
                     } else if (kind == SK_METAL) {                    // material/mod.rs:85-96
                         Vec3 reflected = rtm::reflect(rtm::to_unit(r.dir), rec.normal);
-                        dir = reflected + random_in_unit_sphere(rng) * mat.param;
-                        wgt = ld3(mat.albedo);
+                        dir = reflected + random_in_unit_sphere(rng) * m_param;
+                        wgt = m_albedo;
                         tm = 0.0;                                     // time = 0., mod.rs:91
                     } else if (kind == SK_DIELECTRIC) {               // material/mod.rs:120-147
-                        double refraction_ratio = rec.front_face ? 1.0 / mat.param : mat.param;
+                        double refraction_ratio = rec.front_face ? 1.0 / m_param : m_param;
                         Vec3 unit_direction = rtm::to_unit(r.dir);
                         double cos_theta = rtm::fmin_(rtm::dot(-unit_direction, rec.normal), 1.0);
                         double sin_theta = rtm::sqrt_(1.0 - cos_theta * cos_theta);
@@ -304,7 +430,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                                   : rtm::refract(unit_direction, rec.normal, refraction_ratio);
                         wgt = Vec3(1.0, 1.0, 1.0);
                     } else {                                          // Isotropic, material/mod.rs:207-213
-                        wgt = texture_value(s, mat.tex, rec.u, rec.v, rec.p);
+                        wgt = texture_value_top(s, m_tex, m_tex_kind, m_tex_color, rec.u, rec.v, rec.p);
                         dir = random_in_unit_sphere(rng);
                     }
                     uint32_t nb = a.max_depth - depth;
@@ -507,15 +633,6 @@ struct TStack {
 };
 
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
-// Records are fetched whole and at once — a few 16-byte loads issued back to back and waited for together — never
-// field by field as the arithmetic gets to them: left to itself the compiler sinks each field's load into the branch
-// that uses it, and an arm like Boxes::hit then waits for memory six to ten times in a row (seen in the ISA). The empty
-// asm pins the value: the load cannot move below it, and everything pinned together shares one wait.
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // (records whose size is 8 mod 16)
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <class T>
-RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
 // The fast node step applies (see there): every 1/d finite and non-zero, origin finite, boxes plain.
 RT_DEV void t_flags(TLane &L, bool boxes_plain) {
     L.plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
@@ -952,7 +1069,7 @@ __global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 
                 uint32_t kind = SK_MISS;
                 const uint32_t steps16 = (L.steps > 0xFFFFu ? 0xFFFFu : L.steps) << 16;
                 if (found) {
-                    pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain);
+                    pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain, L.win_mat);
                     kind = L.win_mat >> kMatKindShift;                // (the word came with the winning primitive's record)
                 }
                 pool.kind[slot] = (uint8_t)kind;

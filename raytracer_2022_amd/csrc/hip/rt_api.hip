@@ -225,12 +225,14 @@ struct DeviceGuard {
 template <class T>
 T *upload(const T *src, uint64_t n, std::vector<void *> &owned) {
     // Never hand the kernels a null pool: an empty pool gets one zeroed element.
-    uint64_t bytes = (n ? n : 1) * sizeof(T);
+    // (128 bytes of zeroed slack behind every pool: the shading kernel fetches a fixed 80 bytes from the winning
+    // primitive's record whatever its kind, the last record of a pool included)
+    uint64_t bytes = (n ? n : 1) * sizeof(T) + 128;
     void *p = nullptr;
     RT_HIP(hipMalloc(&p, bytes));
     owned.push_back(p);
+    RT_HIP(hipMemset(p, 0, bytes));
     if (n) RT_HIP(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
-    else RT_HIP(hipMemset(p, 0, bytes));
     return (T *)p;
 }
 
@@ -597,6 +599,23 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.lights = upload(desc->lights, desc->n_lights, sc->owned);
             s.materials = upload(desc->materials, desc->n_materials, sc->owned);
             s.textures = upload(desc->textures, desc->n_textures, sc->owned);
+            {
+                std::vector<MaterialDev> md(desc->n_materials);
+                for (uint32_t i = 0; i < desc->n_materials; i++) {
+                    const rt_material &m = desc->materials[i];
+                    MaterialDev &q = md[i];
+                    std::memset(&q, 0, sizeof q);
+                    q.tex = m.tex;
+                    std::memcpy(q.albedo, m.albedo, sizeof q.albedo);
+                    q.param = m.param;
+                    if (m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC) {
+                        const rt_texture &t = desc->textures[m.tex];
+                        q.tex_kind = t.kind; q.tex_a = t.a; q.tex_b = t.b; q.tex_scale = t.scale;
+                        std::memcpy(q.tex_color, t.color, sizeof q.tex_color);
+                    }
+                }
+                s.materials_dev = upload(md.data(), md.size(), sc->owned);
+            }
             s.images = upload(desc->images, desc->n_images, sc->owned);
             s.image_data = upload(desc->image_data, desc->image_data_bytes, sc->owned);
             s.perlins = upload(desc->perlins, desc->n_perlins, sc->owned);

@@ -1,0 +1,35 @@
+"""Sweep of the traversal scheduler's runtime knobs (rt_debug_set_tuning) on the headline scene: Mrays/s per setting,
+interleaved twice in one process."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, ctypes as C
+import raytracer_2022_amd as rt
+from raytracer_2022_amd import _ffi as F
+
+def run(dev, cam, p, rows, W):
+    pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
+    o = np.empty((len(rows), W, 3)); st = F.rt_stats()
+    F.check(F.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), o.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+    return st.ms
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'final_scene'
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+W = H = 800
+assets = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'assets')
+s = rt.HostScene(name, seed=2022, assets_dir=assets if os.path.isdir(assets) else None)
+cam, bg = s.default_view(W / H)
+rows = np.arange(H, dtype=np.uint32)
+dev = rt.DeviceScene(s.desc)
+pc = rt.make_params(W, H, 20, 50, bg, seed=2022, spp_chunk=1)
+out, st = dev.render(cam, pc, rows, want_stats=True)
+rays = st.rays * (spp / 20.0)
+def Q(q=18, segs=6, shift=2):
+    return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (1 << 24)
+cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (1, 3)]
+p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
+dev.set_tuning(Q()); run(dev, cam, p, rows, W)
+for rep in range(2):
+    for tag, q in cfgs:
+        dev.set_tuning(q)
+        ms = run(dev, cam, p, rows, W)
+        print('%-8s %8.1f ms  %7.1f Mrays/s' % (tag, ms, rays / ms / 1e3), flush=True)
