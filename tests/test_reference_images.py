@@ -1,0 +1,52 @@
+"""Statistical anchor to the reference's own output (build container only: needs /root/reference and PIL).
+
+The reference ships no vectors and is unseeded, so nothing here can be bit-exact — PARITY STAYS UNPINNED. What this does
+pin, against the one artefact the reference holds for BASELINE's headline scene (output/book2/Finanscene.jpg, 800x800,
+rendered by the reference's authors with unknown spp / seed / code version): that the oracle's radiometry is in the
+right place — where the light is, how bright the lit and the unlit parts are relative to each other, that the fog, the
+glass, the earth texture and the box of spheres land where the reference's do. Random box heights and sphere positions
+differ between the two (different RNG), so the comparison is on 8x8 block means of luminance, not pixels."""
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/output/book2/Finanscene.jpg"
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def luminance_blocks(rgb8, n=8):
+    a = np.asarray(rgb8, dtype=np.float64)
+    lum = 0.2126 * a[..., 0] + 0.7152 * a[..., 1] + 0.0722 * a[..., 2]
+    return lum.reshape(n, lum.shape[0] // n, n, lum.shape[1] // n).mean(axis=(1, 3))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference's output images are only in the build container")
+def test_final_scene_agrees_with_the_reference_image_in_the_large(rt, O):
+    Image = pytest.importorskip("PIL.Image")
+    W = H = 800
+    spp = 8
+    s = rt.HostScene("final_scene", seed=2022, assets_dir=ASSETS if os.path.isdir(ASSETS) else None)
+    cam, bg = s.default_view(1.0)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022)
+    rows = np.arange(H, dtype=np.uint32)
+    img = rt.fill_image(O.render_cpu(s.desc, cam, p, rows, n_threads=os.cpu_count() or 4), rows, W, H, spp)
+    ref = np.asarray(Image.open(REF).convert("RGB"))
+    assert ref.shape == img.shape == (H, W, 3)
+    A, B = luminance_blocks(img), luminance_blocks(ref)
+    # the ceiling light: same blocks of the top row saturate in both, and nothing else does
+    assert np.array_equal(A > 200, B > 200) and (A > 200).sum() == 3 and (A > 200)[0].sum() == 3
+    # the layout in the large: block means correlate (measured 0.985 at 16 spp; unrelated scenes give < 0.5)
+    corr = np.corrcoef(A.ravel(), B.ravel())[0, 1]
+    assert corr > 0.96, corr
+    # the lit floor and spheres (bottom half) against the dark back wall (right of the top half): same order of contrast
+    lit_a, dark_a = A[5:, :].mean(), A[1:4, 6:].mean()
+    lit_b, dark_b = B[5:, :].mean(), B[1:4, 6:].mean()
+    assert lit_a > 3 * dark_a and lit_b > 2 * dark_b
+    # exposure: the reference's image carries a floor of ~25 levels in its darkest blocks that v1's black background
+    # (book camera and background, not in v1's main.rs) does not have; above it the two agree
+    assert abs((A.mean() + 20.0) - B.mean()) < 15.0, (A.mean(), B.mean())
+    # the earth texture (left, rows 4-5) is blue-green in both: blue and green exceed red there
+    for im in (img, ref):
+        patch = np.asarray(im[400:560, 40:200], dtype=np.float64).mean(axis=(0, 1))
+        assert patch[2] > patch[0] and patch[1] > patch[0], patch
