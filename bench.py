@@ -431,6 +431,18 @@ def main():
                     "salu_per_valu": rnd(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3),
                 }
                 limiter.append(("valu_issue", roof["valu"]["issue_busy"]))
+            if "wf_shade" in pmc and pmc["wf_shade"].get("SQ_INSTS_VALU"):        # the other kernel of the frame, same figures
+                c2 = pmc["wf_shade"]
+                r2, w2 = hbm_bytes(c2)
+                u2 = c2.get("SQ_THREAD_CYCLES_VALU", 0.0) / (c2.get("SQ_ACTIVE_INST_VALU", 0.0) * 64.0) if c2.get("SQ_ACTIVE_INST_VALU") else None
+                roof["wf_shade"] = {
+                    "device_ms_per_step": rnd(sh_ms, 3), "launch_ms": rnd(sh_ms / n_pass if n_pass else None, 4),
+                    "algorithmic_achieved": rnd(gbs(ab["wf_shade"], sh_ms)), "hbm_counter_achieved": rnd(gbs(r2 + w2, sh_ms)), "unit": "GB/s",
+                    "hbm_counter_frac": frac(gbs(r2 + w2, sh_ms), HBM_PEAK_GBS),
+                    "wave_instructions_per_step": int(c2["SQ_INSTS_VALU"]), "lane_utilisation": rnd(u2, 4),
+                    "issue_busy": rnd(c2["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * 2.4e9 * sh_ms * 1e-3), 4) if sh_ms else None,
+                    "wait_any_over_wave_cycles": rnd(c2.get("SQ_WAIT_ANY", 0.0) / c2["SQ_WAVE_CYCLES"], 4) if c2.get("SQ_WAVE_CYCLES") else None,
+                }
         elif world == 1:
             tc = committed_traffic(args.config, spp, args.spp_chunk)
             if tc:

@@ -317,6 +317,23 @@ int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *par
                      double *d_out_rgb_sum, void *hip_stream, rt_stats *stats);
 int rt_render_wait(rt_scene *scene, void *hip_stream);
 
+/* ---- one call, several GPUs ------------------------------------------------------------------
+ * The reference's main() drives all its workers from one place (main.rs:109-183: spawn, join, concatenate).
+ * Two ways to do the same over GPUs:
+ *   - one process per GPU (what bench.py and torch.distributed do): each process creates its own rt_scene and
+ *     renders its share of the rows (film.py deals them); nothing below is needed;
+ *   - ONE process, ONE call: an rt_scene_set holds a copy of the scene on every device whose bit is set in
+ *     device_mask (bit d = HIP device d); rt_render_multi deals params->row_ids cyclically over those devices
+ *     (entry i goes to the (i mod n)-th of them — with the reference's shuffled row list every device gets the same
+ *     mix of cheap and dear rows), renders the shares concurrently, one host thread and one stream per device, and
+ *     writes out_rgb_sum in row_ids order exactly as rt_render would. Results do not depend on the mask: the RNG is
+ *     keyed per pixel and sample. stats, if given, carries the counters summed over the devices and the longest
+ *     device time. */
+typedef struct rt_scene_set rt_scene_set;
+int rt_scene_set_create(const rt_scene_desc *desc, uint64_t device_mask, rt_scene_set **out);
+int rt_scene_set_destroy(rt_scene_set *set);
+int rt_render_multi(rt_scene_set *set, const rt_camera *cam, const rt_params *params, double *out_rgb_sum, rt_stats *stats);
+
 /* write_color (main.rs:280-299): NaN→0, sqrt(c/spp), clamp [0,0.999], *255.999, floor. */
 void rt_write_color(const double rgb_sum[3], int32_t spp, uint8_t out_rgb[3]);
 /* Device form over n_pixels sums → n_pixels*3 bytes, on hip_stream. */

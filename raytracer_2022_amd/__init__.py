@@ -9,7 +9,7 @@ from . import _ffi
 from ._ffi import RtError, lib, make_ref, ref_index, ref_kind  # noqa: F401
 from .host import (DescBuilder, HostScene, camera_new, fill_image, load_image, make_params, shuffled_rows,  # noqa: F401
                    write_color, write_jpeg)
-from .device import DeviceScene  # noqa: F401
+from .device import DeviceScene, DeviceSceneSet  # noqa: F401
 
-__all__ = ["DescBuilder", "HostScene", "DeviceScene", "camera_new", "fill_image", "make_params", "shuffled_rows",
+__all__ = ["DescBuilder", "HostScene", "DeviceScene", "DeviceSceneSet", "camera_new", "fill_image", "make_params", "shuffled_rows",
            "write_color", "write_jpeg", "load_image", "RtError", "lib", "make_ref", "ref_kind", "ref_index"]

@@ -155,7 +155,7 @@ LIB_PATH = os.environ.get("RT2022_LIB") or os.path.join(_HERE, "librt2022.so")  
 # Every symbol the three headers declare (tests/test_abi.py checks the export table).
 ABI_SYMBOLS = [
     "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_wait", "rt_write_color",
-    "rt_tonemap_device", "rt_last_error", "rt_abi_version",
+    "rt_tonemap_device", "rt_last_error", "rt_abi_version", "rt_scene_set_create", "rt_scene_set_destroy", "rt_render_multi",
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
     "rtb_last_error", "rtb_abi_sizes",
@@ -187,6 +187,9 @@ def lib():
     L.rt_tonemap_device.argtypes = [vp, u64, i32, vp, vp]
     L.rt_last_error.restype = C.c_char_p
     L.rt_abi_version.restype = u32
+    L.rt_scene_set_create.argtypes = [P(rt_scene_desc), u64, P(vp)]
+    L.rt_scene_set_destroy.argtypes = [vp]
+    L.rt_render_multi.argtypes = [vp, P(rt_camera), P(rt_params), P(dbl), P(rt_stats)]
     L.rtb_scene_build.argtypes = [C.c_char_p, u64, C.c_char_p, i32, P(vp)]
     L.rtb_scene_free.argtypes = [vp]
     L.rtb_scene_free.restype = None

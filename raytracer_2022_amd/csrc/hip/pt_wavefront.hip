@@ -270,6 +270,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __shared__ uint8_t new_kind[S];      // the slots' next state (| list class << 4), written back in one coalesced sweep
     __shared__ uint32_t bins[kListBins];
     __shared__ uint8_t new_oct[S];       // direction octant of the slot's next ray (second sort key of the list)
+    __shared__ uint16_t fresh_q[S];      // slots that want a new path (| 0x8000: the slot holds an item whose state counts)
+    __shared__ uint32_t n_fresh;
     const RenderArgs &a = *ap;
     const PoolView pv{pool};
     const uint32_t base = blockIdx.x * (uint32_t)S;
@@ -284,6 +286,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     if (tid < kLdsLights && tid < s.n_lights) lights_lds[tid] = fetch_light(s, tid);
     auto light_at = [&](uint32_t li) { return li < kLdsLights ? lights_lds[li] : fetch_light(s, li); };
     if (tid < SK_COUNT) hist[tid] = 0;
+    if (tid == 0) n_fresh = 0;
     __syncthreads();
     // Counting sort of the block's slots by kind (idle slots and nothing else are dropped).
     uint32_t my_kind[S / kBlock];
@@ -463,10 +466,51 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             rng.draws = 0;
         }
 
-        // Next sample of the item, or the next item (main.rs:140-152).
-        bool want_path = on && (kind == SK_FRESH || ended);
-        if (want_path) {
-            bool have_item = kind != SK_FRESH;
+        // A slot whose path has ended (or that never had one) gets its next path in the second sweep below, where all
+        // such slots of the segment sit side by side: aiming a camera ray (three hashes, the lens rejection loop, five
+        // divisions) is the longest stretch of this kernel, and here it would run for the fifth of the lanes that need it.
+        const bool want_path = on && (kind == SK_FRESH || ended);
+        {
+            const unsigned long long wm = __ballot(want_path);
+            if (wm) {
+                const int leader = __ffsll((long long)wm) - 1;
+                uint32_t qbase = 0;
+                if ((int)lane == leader) qbase = atomicAdd(&n_fresh, (uint32_t)__popcll(wm));
+                qbase = (uint32_t)__shfl((int)qbase, leader);
+                if (want_path) fresh_q[qbase + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] =
+                    (uint16_t)((slot - base) | ((kind != SK_FRESH && !single) ? 0x8000u : 0u));
+            }
+        }
+
+        if (on && alive) {
+            cnt.ray();                                                // world.hit(r, 0.001, f64::MAX), main.rs:243
+            pv.store_ray(slot, r, rng.s);
+            stt.depth = depth | (tainted << 31);
+            store_state(pool, slot, stt, false);
+            uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
+            new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
+            new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
+        }
+    }
+
+    // Second sweep: the next sample of the item, or the next item (main.rs:140-152), for every slot that asked.
+    // (The barrier also makes the first sweep's pixel sums visible to whichever thread finishes the item here.)
+    __syncthreads();
+    const uint32_t n_want = n_fresh;
+    for (uint32_t j0 = 0; j0 < n_want; j0 += kBlock) {
+        const uint32_t j = j0 + tid;
+        const bool on = j < n_want;
+        const uint32_t e = on ? (uint32_t)fresh_q[j] : 0u;
+        const uint32_t slot = base + (e & 0x0FFFu);
+        bool alive = false;
+        Ray r;
+        Rng rng;
+        uint32_t depth = 0;
+        SlotState stt{};
+        if (on) {
+            // (one-sample items: the item is always finished, nothing of the old state is needed)
+            bool have_item = (e & 0x8000u) != 0;
+            if (have_item) stt = load_state(pool, slot);
             uint32_t smp = have_item ? stt.smp : 0u, smp_end = have_item ? stt.smp_end : 0u;
             for (int guard = 0; guard < 1 << 20; guard++) {           // loops only through degenerate items (spp or depth 0)
                 bool need = !have_item || smp == smp_end;
@@ -526,9 +570,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 double u = ((double)px + rand_u) / (double)(a.width - 1);
                 double v = ((double)py + rand_v) / (double)(a.height - 1);
                 r = get_ray(a.cam, u, v, rng);
-                expect = 0;
                 depth = a.max_depth;
-                tainted = 0;
                 smp++;
                 cnt.path();
                 cnt.draws(rng.draws);                                 // words drawn while aiming the camera ray
@@ -539,16 +581,12 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             }
             stt.smp = smp;
             stt.smp_end = smp_end;
-        }
-
-        if (on) {
             if (alive) {
                 cnt.ray();                                            // world.hit(r, 0.001, f64::MAX), main.rs:243
                 pv.store_ray(slot, r, rng.s);
-                stt.depth = depth | (tainted << 31);
-                store_state(pool, slot, stt, want_path);
-                uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
-                new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
+                stt.depth = depth;                                    // (a fresh tape: nothing tainted)
+                store_state(pool, slot, stt, true);
+                new_kind[slot - base] = (uint8_t)SK_TRACE;            // (a camera ray goes with the short ones: list class 0)
                 new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
             }
         }

@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -716,6 +717,109 @@ int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params, do
         if (d_rows) (void)hipFree(d_rows);
         if (d_out) (void)hipFree(d_out);
         return rc;
+    });
+}
+
+// ---- one call, several GPUs (rt2022.h) ----------------------------------------------------------------------
+struct rt_scene_set {
+    std::vector<int> devices;
+    std::vector<rt_scene *> scenes;
+};
+
+int rt_scene_set_create(const rt_scene_desc *desc, uint64_t device_mask, rt_scene_set **out) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(desc && out, RT_ERR_INVALID, "rt_scene_set_create: null argument");
+        RT_REQUIRE(device_mask != 0, RT_ERR_INVALID, "rt_scene_set_create: empty device mask");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        RT_REQUIRE(e == hipSuccess && ndev > 0, RT_ERR_DEVICE, "rt_scene_set_create: no HIP device available (the path has no CPU fallback)");
+        RT_REQUIRE(ndev >= 64 || (device_mask >> ndev) == 0, RT_ERR_DEVICE, "rt_scene_set_create: device_mask names a device this process cannot see");
+        int prev = 0;
+        RT_HIP(hipGetDevice(&prev));
+        rt_scene_set *set = new rt_scene_set();
+        int rc = RT_OK;
+        for (int d = 0; d < ndev && d < 64 && rc == RT_OK; d++) {
+            if (!((device_mask >> d) & 1ull)) continue;
+            if (hipSetDevice(d) != hipSuccess) { set_error("rt_scene_set_create: hipSetDevice failed"); rc = RT_ERR_DEVICE; break; }
+            rt_scene *sc = nullptr;
+            rc = rt_scene_create(desc, &sc);                   // (leaves its own message on failure)
+            if (rc == RT_OK) { set->devices.push_back(d); set->scenes.push_back(sc); }
+        }
+        (void)hipSetDevice(prev);
+        if (rc != RT_OK) {
+            std::string msg = rt_last_error();
+            for (rt_scene *sc : set->scenes) (void)rt_scene_destroy(sc);
+            delete set;
+            set_error(msg);
+            return rc;
+        }
+        *out = set;
+        return RT_OK;
+    });
+}
+
+int rt_scene_set_destroy(rt_scene_set *set) {
+    return guarded([&]() -> int {
+        if (!set) return RT_OK;
+        for (rt_scene *sc : set->scenes) (void)rt_scene_destroy(sc);
+        delete set;
+        return RT_OK;
+    });
+}
+
+int rt_render_multi(rt_scene_set *set, const rt_camera *cam, const rt_params *params, double *out_rgb_sum, rt_stats *stats) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(set && !set->scenes.empty() && cam && params, RT_ERR_INVALID, "rt_render_multi: null argument");
+        RT_REQUIRE(params->n_rows == 0 || (params->row_ids && out_rgb_sum), RT_ERR_INVALID, "rt_render_multi: null rows or output");
+        const size_t n = set->scenes.size();
+        const size_t row_doubles = (size_t)params->width * 3;
+        struct Share {
+            std::vector<uint32_t> rows;
+            std::vector<double> out;
+            rt_stats st;
+            int rc = RT_OK;
+            std::string err;
+        };
+        std::vector<Share> shares(n);
+        for (uint32_t i = 0; i < params->n_rows; i++) shares[i % n].rows.push_back(params->row_ids[i]);
+        std::vector<std::thread> workers;
+        for (size_t k = 0; k < n; k++) {
+            workers.emplace_back([&, k]() {
+                Share &sh = shares[k];
+                std::memset(&sh.st, 0, sizeof sh.st);
+                rt_params p = *params;
+                p.n_rows = (uint32_t)sh.rows.size();
+                p.row_ids = sh.rows.data();
+                sh.out.resize(sh.rows.size() * row_doubles);
+                // (rt_render makes the scene's device current for this thread and leaves the caller's alone)
+                sh.rc = rt_render(set->scenes[k], cam, &p, sh.out.data(), &sh.st);
+                if (sh.rc != RT_OK) sh.err = rt_last_error();
+            });
+        }
+        for (std::thread &t : workers) t.join();
+        for (size_t k = 0; k < n; k++)
+            if (shares[k].rc != RT_OK) throw Fail{shares[k].rc, "rt_render_multi: device " + std::to_string(set->devices[k]) + ": " + shares[k].err};
+        std::vector<size_t> taken(n, 0);
+        for (uint32_t i = 0; i < params->n_rows; i++) {
+            Share &sh = shares[i % n];
+            std::memcpy(out_rgb_sum + (size_t)i * row_doubles, sh.out.data() + taken[i % n]++ * row_doubles, row_doubles * sizeof(double));
+        }
+        if (stats) {
+            rt_stats tot;
+            std::memset(&tot, 0, sizeof tot);
+            for (const Share &sh : shares) {
+                tot.paths += sh.st.paths; tot.rays += sh.st.rays; tot.node_visits += sh.st.node_visits;
+                for (int k = 0; k < RT_KIND_COUNT; k++) tot.prim_tests[k] += sh.st.prim_tests[k];
+                tot.light_pdf_tests += sh.st.light_pdf_tests; tot.rng_draws += sh.st.rng_draws;
+                tot.ms = sh.st.ms > tot.ms ? sh.st.ms : tot.ms;
+                tot.trace_ms = sh.st.trace_ms > tot.trace_ms ? sh.st.trace_ms : tot.trace_ms;
+                tot.shade_ms = sh.st.shade_ms > tot.shade_ms ? sh.st.shade_ms : tot.shade_ms;
+                tot.spp_chunk = sh.st.spp_chunk; tot.passes = sh.st.passes > tot.passes ? sh.st.passes : tot.passes;
+                tot.pool_slots += sh.st.pool_slots;
+            }
+            *stats = tot;
+        }
+        return RT_OK;
     });
 }
 

@@ -72,3 +72,34 @@ class DeviceScene:
             self.close()
         except Exception:
             pass
+
+
+class DeviceSceneSet:
+    """rt_scene_set: a copy of the scene on every device of `device_mask`, rendered by ONE call (rt_render_multi)."""
+
+    def __init__(self, desc, device_mask=1):
+        self._h = C.c_void_p()
+        F.check(F.lib().rt_scene_set_create(C.byref(desc), device_mask, C.byref(self._h)))
+
+    def render(self, cam, params, row_ids, want_stats=False):
+        rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
+        p = F.rt_params.from_buffer_copy(params)
+        p.n_rows = len(rows)
+        p.row_ids = rows.ctypes.data
+        if want_stats:
+            p.flags |= F.RT_FLAG_COUNTERS
+        out = np.empty((len(rows), p.width, 3), dtype=np.float64)
+        st = F.rt_stats()
+        F.check(F.lib().rt_render_multi(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+        return (out, st) if want_stats else out
+
+    def close(self):
+        if self._h:
+            F.lib().rt_scene_set_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

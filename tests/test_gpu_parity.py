@@ -467,3 +467,68 @@ def test_full_size_properties_of_the_headline_config(rt, O):
     assert np.array_equal(bits(full[:6]), bits(ref))
     img = rt.fill_image(full, rows, W, H, 8)
     assert img.shape == (H, W, 3) and img.max() == 255 and img.mean() > 5
+
+
+def test_one_call_over_a_device_mask(rt, O):
+    """rt_render_multi (SURVEY.md §8b "Threading": one call drives every device of the mask): rows dealt cyclically
+    over the devices, shares rendered concurrently, output in row_ids order — the same bits as rt_render whatever the
+    mask. One GPU here exercises the dealing and the reassembly; with more visible the mask grows."""
+    import torch
+    s = rt.HostScene("cornell_smoke", seed=4)
+    W, H, spp = 48, 40, 5
+    cam, bg = s.default_view(W / H)
+    p = rt.make_params(W, H, spp, 50, bg, seed=4, spp_chunk=2)
+    rows = rt.shuffled_rows(H, 6)
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows, n_threads=4, want_stats=True)
+    ndev = torch.cuda.device_count()
+    for mask in sorted({1, (1 << min(ndev, 2)) - 1, (1 << ndev) - 1}):
+        group = rt.DeviceSceneSet(s.desc, mask)
+        out, st = group.render(cam, p, rows, want_stats=True)
+        assert st.as_dict() == st_ref.as_dict(), mask
+        assert np.array_equal(bits(out), bits(ref)), mask
+        assert np.array_equal(bits(group.render(cam, p, rows[:7])), bits(ref[:7])), mask      # fewer rows than a full deal
+        assert group.render(cam, p, rows[:0]).shape == (0, W, 3)
+        group.close()
+    with pytest.raises(rt.RtError) as e:                              # a device this process cannot see
+        rt.DeviceSceneSet(s.desc, 1 << ndev)
+    assert e.value.code == F.RT_ERR_DEVICE
+    with pytest.raises(rt.RtError):
+        rt.DeviceSceneSet(s.desc, 0)
+
+
+def test_kernel_times_and_run_report(rt):
+    """rt_stats says how the call ran (chunk, passes, pool) and, on request, the device time of the two kernels."""
+    s = rt.HostScene("final_scene", seed=2022)
+    W = H = 96
+    cam, bg = s.default_view(1.0)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(W, H, 6, 50, bg, seed=1, spp_chunk=0, flags=F.RT_FLAG_KERNEL_TIMES)
+    rows = np.arange(H, dtype=np.uint32)
+    pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
+    out = np.empty((H, W, 3)); st = F.rt_stats()
+    F.check(rt.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+    assert st.spp_chunk == 6 and st.passes > 5 and st.pool_slots >= W * H // 64 * 64
+    assert 0 < st.trace_ms < st.ms and 0 < st.shade_ms < st.ms and st.trace_ms + st.shade_ms <= st.ms * 1.05
+    p.flags = 0
+    st2 = F.rt_stats()
+    pr = F.rt_params.from_buffer_copy(p); pr.n_rows = len(rows); pr.row_ids = rows.ctypes.data
+    out2 = np.empty((H, W, 3))
+    F.check(rt.lib().rt_render(dev._h, C.byref(cam), C.byref(pr), out2.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st2)))
+    assert st2.trace_ms == 0 and st2.shade_ms == 0 and np.array_equal(bits(out), bits(out2))
+
+
+def test_device_resident_row_ids_are_checked(rt):
+    import torch
+    s = rt.HostScene("cornell_box")
+    cam, bg = s.default_view(1.0)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(16, 16, 1, 5, bg)
+    d_rows = torch.tensor([0, 5, 16], dtype=torch.int32, device="cuda")      # 16 is one past the last row
+    d_out = torch.zeros((3, 16, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(rt.RtError) as e:
+        dev.render_device(cam, p, d_rows.data_ptr(), 3, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert e.value.code == F.RT_ERR_INVALID
+    d_rows[2] = 15
+    dev.render_device(cam, p, d_rows.data_ptr(), 3, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    dev.wait(torch.cuda.current_stream().cuda_stream)
+    assert torch.isfinite(d_out).all()
