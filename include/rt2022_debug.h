@@ -20,7 +20,7 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  *         vote (1..64);
  *   8-15  (unused: two sphere tests per turn and a tail factor of 2 are built in);
  *   16-19 pool size of the wavefront engine: segments of 4096 path slots per resident traversal
- *         workgroup (1..8, default 6);
+ *         workgroup (1..8, default 8);
  *   20-23 s: every segment's ray list is ordered longest-first by (expected node steps) >> s, 0 = slot order;
  *   24-27 groups the pool is cut into, each alternating its passes on a stream of its own (1..8, default 1);
  *   28    (unused);

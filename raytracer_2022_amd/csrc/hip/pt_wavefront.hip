@@ -261,6 +261,18 @@ RT_DEV Vec3 texture_value_top(const SceneDev &s, uint32_t tex, uint32_t tex_kind
 // =====================================================================================
 // Shade pass.
 // =====================================================================================
+// Section clock of the shade pass (diagnostic build -DRT2022_SHADE_PROBE only; tools/shade_probe.sh): wave 0's lane 0 of
+// every workgroup adds the wall-clock ticks it spent in each section to pool.dbg[64 + section].
+#ifdef RT2022_SHADE_PROBE
+#define SP_DECL unsigned long long sp_t = wall_clock64(), sp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SP_MARK(i) do { unsigned long long sp_n = wall_clock64(); sp_acc[i] += sp_n - sp_t; sp_t = sp_n; } while (0)
+#define SP_FLUSH() do { if (tid == 0 && pool.dbg) for (int sp_i = 0; sp_i < 10; sp_i++) atomicAdd(&pool.dbg[64 + sp_i], sp_acc[sp_i]); } while (0)
+#else
+#define SP_DECL do {} while (0)
+#define SP_MARK(i) do {} while (0)
+#define SP_FLUSH() do {} while (0)
+#endif
+
 template <bool STATS>
 __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool, const uint32_t parity) {
     __shared__ uint32_t hist[SK_COUNT];
@@ -285,6 +297,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __shared__ LightRec lights_lds[kLdsLights];
     if (tid < kLdsLights && tid < s.n_lights) lights_lds[tid] = fetch_light(s, tid);
     auto light_at = [&](uint32_t li) { return li < kLdsLights ? lights_lds[li] : fetch_light(s, li); };
+    SP_DECL;
     if (tid < SK_COUNT) hist[tid] = 0;
     if (tid == 0) n_fresh = 0;
     __syncthreads();
@@ -310,6 +323,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = ((uint32_t)(i * kBlock) + tid) | (k << 16);
     }
     __syncthreads();
+    SP_MARK(0);                                                      // 0: counting sort
     const uint32_t total = n_sorted;
     const Vec3 background = ld3(a.background);
     // One sample per work item (spp_chunk = 1): the item's running sum needs no place of its own in the pool.
@@ -361,6 +375,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 t_pin(md0); t_pin(md1); t_pin(md2); t_pin(md3); t_pin(md4);
             }
         }
+        SP_MARK(1);                                                  // 1: slot, hit, primitive and material fetches
         // MaterialDev: tex, tex_kind | albedo | param | tex_color | tex_scale | tex_a, tex_b
         const uint32_t m_tex = (uint32_t)rtm::d2u(md0.x), m_tex_kind = (uint32_t)(rtm::d2u(md0.x) >> 32);
         const Vec3 m_albedo(md0.y, md1.x, md1.y), m_tex_color(md2.y, md3.x, md3.y);
@@ -389,6 +404,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 }
                 HitRec rec;
                 winner_record_regs(s, r, w, prim, rec, want_uv);
+                SP_MARK(2);                                           // 2: the winner's hit record
                 if (kind == SK_LIGHT) {                               // emitted; scatter = None (material/mod.rs:16-18,174-180)
                     Lterm = rec.front_face ? texture_value_top(s, m_tex, m_tex_kind, m_tex_color, rec.u, rec.v, rec.p) : Vec3(0.0, 0.0, 0.0);
                     ended = true;
@@ -445,6 +461,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     else alive = true;
                 }
             }
+            SP_MARK(3);                                               // 3: emitted / scatter / pdfs / tape record
             if (ended) {
                 uint32_t nb = a.max_depth - depth;
                 // Unwinding from an exact zero through records with finite weights and usable pdfs gives 0 + (w * 0) / p =
@@ -466,6 +483,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             rng.draws = 0;
         }
 
+        SP_MARK(4);                                                   // 4: unwinding and the pixel
         // A slot whose path has ended (or that never had one) gets its next path in the second sweep below, where all
         // such slots of the segment sit side by side: aiming a camera ray (three hashes, the lens rejection loop, five
         // divisions) is the longest stretch of this kernel, and here it would run for the fifth of the lanes that need it.
@@ -493,6 +511,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         }
     }
 
+    SP_MARK(5);                                                      // 5: queueing, stores of the bounce
     // Second sweep: the next sample of the item, or the next item (main.rs:140-152), for every slot that asked.
     // (The barrier also makes the first sweep's pixel sums visible to whichever thread finishes the item here.)
     __syncthreads();
@@ -591,6 +610,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
             }
         }
     }
+    SP_MARK(6);                                                      // 6: second sweep (new paths)
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
     if (tid < kListBins) bins[tid] = 0;
     __syncthreads();
@@ -627,6 +647,8 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     for (int i = 0; i < S / kBlock; i++)
         if (my_key[i] < kListBins) pool.list[base + atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
     if (STATS) cnt.flush_wave(a.stats);
+    SP_MARK(7);                                                      // 7: kinds written back, ray list built
+    SP_FLUSH();
 }
 
 // =====================================================================================
@@ -743,10 +765,15 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
 
 } // namespace
 
+// Resident traversal workgroups per CU a variant is built and launched for (= waves per SIMD = its VGPR budget):
+// the sphere-only kernel needs 80 VGPRs and runs six (C2: +4.5 % over four), the full kernels four.
+constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
+    return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? 6 : kTraceBlocksPerCU;
+}
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
-__global__ void __launch_bounds__(kBlock, STACK > 32 ? 2 : STATS ? 3 : (STACK > 22 || (FEAT & kFeatMisc)) ? 4 : kTraceBlocksPerCU) wf_trace(const SceneDev s, const WfPool pool,
+__global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT)) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
@@ -1217,7 +1244,7 @@ template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
 static void launch_trace(const WfLaunch &w, uint32_t parity) {
     // A persistent grid: as many workgroups as the kernel's launch bounds keep resident, never more than the work
     // (a segment holds at most 4096 / kChunk chunks for the 4 waves of a workgroup).
-    constexpr uint32_t per_cu = STACK > 32 ? 2 : STATS ? 3 : (STACK > 22 || (FEAT & kFeatMisc)) ? 4 : kTraceBlocksPerCU;
+    constexpr uint32_t per_cu = trace_blocks_per_cu(STACK, STATS, FEAT);
     uint32_t grid = per_cu * (w.pool.n_cus ? w.pool.n_cus : 1u);
     const uint32_t most = w.blocks * ((uint32_t)S / kChunk / 4u);
     if (grid > most) grid = most;
@@ -1420,6 +1447,18 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         (void)hipStreamSynchronize(stream);
         return e;
     }
+#ifdef RT2022_SHADE_PROBE
+    if (pool.dbg) {
+        unsigned long long h[10];
+        if (hipMemcpy(h, pool.dbg + 64, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            double tot = 0; for (int i = 0; i < 8; i++) tot += (double)h[i];
+            fprintf(stderr, "shade probe (ticks of wave 0, all workgroups and passes; share):");
+            for (int i = 0; i < 8; i++) fprintf(stderr, " [%d] %.3f", i, tot > 0 ? (double)h[i] / tot : 0.0);
+            fprintf(stderr, "  total %.3e ticks\n", tot);
+        }
+        (void)hipMemset(pool.dbg + 64, 0, 10 * sizeof(unsigned long long));
+    }
+#endif
     uint32_t fault = 0;
     if ((e = hipMemcpy(&fault, pool.fault, sizeof fault, hipMemcpyDeviceToHost)) != hipSuccess) return e;
     if (out_fault) *out_fault = fault;

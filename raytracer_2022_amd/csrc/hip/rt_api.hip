@@ -273,7 +273,7 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(6 * 4096 / kSlotsPerBlock > 0 ? 6 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 6 segments per resident trace workgroup; list classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(8 * 4096 / kSlotsPerBlock > 0 ? 8 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 8 segments per resident trace workgroup (4 per CU: 8192 segments = 33.5 M slots); list classes of 4 node steps
     uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
@@ -423,7 +423,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Wavefront engine: pool of path slots, shade / trace passes until it drains.
         // Pool = segments of 4096 path slots (one shade workgroup each). The trace pass is a persistent grid of
         // kTraceBlocksPerCU workgroups per CU that draws on all segments' ray lists; the pool holds `segs` segments
-        // per such workgroup (default 6: 31 M slots, ~58 GB with a depth-50 tape — measured optimum of 2.5-10 K
+        // per such workgroup (default 8: 33.5 M slots, ~62 GB with a depth-50 tape — measured optimum of 2.5-10 K
         // segments on the headline scene; sized for 288 GB of HBM).
         uint32_t segs = (sc->node_quorum >> 16) & 0xFu;
         if (segs < 1) segs = 1;
@@ -454,6 +454,10 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         if (w.gs.n < 1) w.gs.n = 1;
         if (w.gs.n > kMaxGroups) w.gs.n = kMaxGroups;
         w.pool.dbg = timing ? w.pool_dbg : nullptr;
+#ifdef RT2022_SHADE_PROBE
+        w.pool.dbg = w.pool_dbg;                                  // (diagnostic build: the shade pass's section clock)
+        RT_HIP(hipMemsetAsync(w.pool_dbg + 64, 0, 10 * sizeof(unsigned long long), stream));
+#endif
         if (timing) for (double &t : sc->pass_timing) t = 0.0;
         a.tape = nullptr;
         RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));

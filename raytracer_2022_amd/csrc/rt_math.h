@@ -12,8 +12,20 @@
 //
 // The transcendental kernels restate the published fdlibm / FreeBSD msun
 // algorithms (k_sin.c, k_cos.c, e_rem_pio2.c medium path, e_acos.c, s_atan.c,
-// e_atan2.c, e_log.c); accuracy < 1 ulp in the ranges the path uses, checked
-// against libm in tests/test_math.py.
+// e_atan2.c, e_log.c) with their coefficient tables; accuracy < 1 ulp in the
+// ranges the path uses, checked against libm in tests/test_math.py. Those
+// files carry this notice, which is preserved here as it asks:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+//
+// (third-party public code, not part of the reference repository)
 #ifndef RT2022_RT_MATH_H
 #define RT2022_RT_MATH_H
 

@@ -18,7 +18,7 @@ class DeviceScene:
         F.check(F.lib().rt_debug_scene_info(self._h, C.byref(need), C.byref(blocks)))
         return {"stack_need": need.value, "grid_blocks": blocks.value}
 
-    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (6 << 16) | (2 << 20) | (1 << 24), vote_weights=0x22222221):
+    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24), vote_weights=0x22222221):
         F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))
 
     def set_engine(self, engine, max_pool_blocks=0):

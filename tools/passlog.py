@@ -11,7 +11,7 @@ s = rt.HostScene('final_scene', seed=2022)
 cam, bg = s.default_view(1.0)
 rows = rt.shuffled_rows(H, 1)
 dev = rt.DeviceScene(s.desc)
-dev.set_tuning((18 | (1 << 8) | (2 << 12) | (6 << 16) | (2 << 20) | (1 << 24)) | (1 << 29))      # the defaults + the probe
+dev.set_tuning((18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24)) | (1 << 29))      # the defaults + the probe
 p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
 out = dev.render(cam, p, rows)
 t = dev.pass_timing()
