@@ -118,18 +118,20 @@ constexpr uint32_t kMatKindShift = 24, kMatIndexMask = (1u << kMatKindShift) - 1
 #define RT2022_SLOTS_PER_SEGMENT 4096
 #endif
 constexpr int kSlotsPerBlock = RT2022_SLOTS_PER_SEGMENT;     // (a multiple of 256, at most 32768: list entries are u16)
+constexpr uint64_t kRecBytes = 128, kRecDoubles = kRecBytes / 8, kRecWords = kRecBytes / 4;      // the slot record
 struct WfPool {
     uint32_t n_slots;
     uint32_t n_blocks;      // segments
-    uint8_t *kind;          // [P]    what the slot waits for (SlotKind)
-    // One 64-byte record per slot: {ox oy oz dx dy dz tm, rng state} — exactly one cache line,
-    // so a lane fetches its ray with four 16-byte loads whatever order the slots are visited in.
-    double *ray;            // [P][8]
-    // One 32-byte record per slot: {t (f64), leaf ref, box face | movers << 4 | node steps << 16, 4 mover refs}.
-    uint32_t *hit;          // [P][8]
-    // One 32-byte record per slot: {item = pixel slot * n_chunks + chunk (u64), next sample, end
-    // sample, remaining depth, px, py, frame}.
-    uint32_t *state;        // [P][8]
+    uint8_t *kind;          // [P]    what a listed slot waits for (SlotKind), BY POSITION ON ITS SEGMENT'S RAY LIST (see `list`)
+    // ONE 128-byte record per slot = one cache line, three parts (`ray`, `hit`, `state` point at their part of slot 0;
+    // stride kRecDoubles doubles / kRecWords words): the shade pass, which visits slots in sorted order, then pulls one
+    // line per slot instead of one line from each of three arrays (measured: shade's HBM reads per ray segment).
+    //   +0   ray:   {ox oy oz dx dy dz tm, rng state}                                                        64 B
+    //   +64  hit:   {t (f64), leaf ref, box face | movers << 4 | node steps << 16, 3 mover refs, 4th ref or material word}   32 B
+    //   +96  state: {item = pixel slot * n_chunks + chunk (u64), next sample, end sample, remaining depth, px, py, frame}    32 B
+    double *ray;
+    uint32_t *hit;
+    uint32_t *state;
     double *pixel_sum;      // [P][4]  running sum of the item (4th double unused)
     double *tape;           // [P][tape_cap][4] bounce records {w.x, w.y, w.z, p}
     uint32_t tape_cap;      // records per slot (>= max_depth)

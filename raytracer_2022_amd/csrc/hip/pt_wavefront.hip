@@ -60,27 +60,27 @@ struct PoolView {
     const WfPool &p;
     // Ray + RNG state: one 64-byte line per slot.
     RT_DEV Ray load_ray(uint32_t slot, uint64_t &rng_state) const {
-        const double2 *q = reinterpret_cast<const double2 *>(p.ray + (uint64_t)slot * 8);
+        const double2 *q = reinterpret_cast<const double2 *>(p.ray + (uint64_t)slot * kRecDoubles);
         double2 a = q[0], b = q[1], c = q[2], d = q[3];
         rng_state = rtm::d2u(d.y);
         return Ray(Vec3(a.x, a.y, b.x), Vec3(b.y, c.x, c.y), d.x);
     }
     RT_DEV Ray load_ray(uint32_t slot) const { uint64_t unused; return load_ray(slot, unused); }
     RT_DEV void store_ray(uint32_t slot, const Ray &r, uint64_t rng_state) const {
-        double2 *q = reinterpret_cast<double2 *>(p.ray + (uint64_t)slot * 8);
+        double2 *q = reinterpret_cast<double2 *>(p.ray + (uint64_t)slot * kRecDoubles);
         q[0] = make_double2(r.orig.x, r.orig.y);
         q[1] = make_double2(r.orig.z, r.dir.x);
         q[2] = make_double2(r.dir.y, r.dir.z);
         q[3] = make_double2(r.tm, rtm::u2d(rng_state));
     }
-    RT_DEV void store_rng(uint32_t slot, uint64_t rng_state) const { p.ray[(uint64_t)slot * 8 + 7] = rtm::u2d(rng_state); }
+    RT_DEV void store_rng(uint32_t slot, uint64_t rng_state) const { p.ray[(uint64_t)slot * kRecDoubles + 7] = rtm::u2d(rng_state); }
     // Winner of the traversal: one 32-byte record per slot.
     // meta = box face | movers << 4 | node steps of the traversal << 16 (the shade pass orders the next
     // trace pass by them); a miss stores nothing (its path ends).
     // Second half = the movers enclosing the leaf; its last word holds the leaf's material word instead whenever the
     // chain leaves it free (fewer than four movers): the shade pass then needs no look at the primitive for it.
     RT_DEV void store_hit(uint32_t slot, double t, uint32_t leaf, uint32_t meta, const Chain &ch, uint32_t mat_word) const {
-        u32x4 *q = reinterpret_cast<u32x4 *>(p.hit + (uint64_t)slot * 8);
+        u32x4 *q = reinterpret_cast<u32x4 *>(p.hit + (uint64_t)slot * kRecWords);
         uint64_t tb = rtm::d2u(t);
         q[0] = (u32x4){(uint32_t)tb, (uint32_t)(tb >> 32), leaf, meta};
         q[1] = (u32x4){ch.c0, ch.c1, ch.c2, ch.n >= 4u ? ch.c3 : mat_word};
@@ -131,7 +131,7 @@ struct SlotState {
     uint32_t smp, smp_end, depth, px, py, frame;
 };
 RT_DEV SlotState load_state(const WfPool &p, uint32_t slot) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p.state + (uint64_t)slot * 8);
+    const uint4 *q = reinterpret_cast<const uint4 *>(p.state + (uint64_t)slot * kRecWords);
     uint4 a = q[0], b = q[1];
     SlotState st;
     st.item = ((uint64_t)a.y << 32) | a.x;
@@ -140,7 +140,7 @@ RT_DEV SlotState load_state(const WfPool &p, uint32_t slot) {
 }
 // (A bounce changes the depth only: the first half is rewritten when a new sample or item starts.)
 RT_DEV void store_state(const WfPool &p, uint32_t slot, const SlotState &st, bool whole) {
-    uint4 *q = reinterpret_cast<uint4 *>(p.state + (uint64_t)slot * 8);
+    uint4 *q = reinterpret_cast<uint4 *>(p.state + (uint64_t)slot * kRecWords);
     if (whole) q[0] = make_uint4((uint32_t)st.item, (uint32_t)(st.item >> 32), st.smp, st.smp_end);
     q[1] = make_uint4(st.depth, st.px, st.py, st.frame);
 }
@@ -301,13 +301,20 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     if (tid < SK_COUNT) hist[tid] = 0;
     if (tid == 0) n_fresh = 0;
     __syncthreads();
-    // Counting sort of the block's slots by kind (idle slots and nothing else are dropped).
-    uint32_t my_kind[S / kBlock];
+    // Counting sort by kind of the slots that carried a ray through the trace pass: the entries of the segment's list
+    // (written by the previous shade pass, or by wf_init: every slot in use, FRESH) with the kind the trace pass left
+    // at the same position. Slots not on the list are idle. (Kinds live by list position, not by slot: the lanes of a
+    // traversal wave take neighbouring entries, so their one-byte results land in the same cache lines at about the same
+    // time instead of dirtying a line per byte all over the segment.)
+    const uint32_t n_listed = pool.list_n[blockIdx.x] < (uint32_t)S ? pool.list_n[blockIdx.x] : (uint32_t)S;
+    uint32_t my_kind[S / kBlock], my_slot[S / kBlock];
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
-        uint32_t k = pool.kind[base + i * kBlock + tid];
-        my_kind[i] = k;
-        new_kind[i * kBlock + tid] = (uint8_t)SK_IDLE;
+        const uint32_t e = (uint32_t)(i * kBlock) + tid;
+        uint32_t k = SK_IDLE, ls = 0;
+        if (e < n_listed) { k = pool.kind[base + e]; ls = pool.list[base + e]; }
+        my_kind[i] = k; my_slot[i] = ls;
+        new_kind[e] = (uint8_t)SK_IDLE;
         if (k != SK_IDLE) atomicAdd(&hist[k], 1u);
     }
     __syncthreads();
@@ -320,7 +327,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t k = my_kind[i];
-        if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = ((uint32_t)(i * kBlock) + tid) | (k << 16);
+        if (k != SK_IDLE) sorted[atomicAdd(&cursor[k], 1u)] = my_slot[i] | (k << 16);
     }
     __syncthreads();
     SP_MARK(0);                                                      // 0: counting sort
@@ -360,7 +367,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                 uint64_t rs;
                 r = pv.load_ray(slot, rs);
                 rng = Rng(rs);
-                const u32x4 *hq = reinterpret_cast<const u32x4 *>(pool.hit + (uint64_t)slot * 8);
+                const u32x4 *hq = reinterpret_cast<const u32x4 *>(pool.hit + (uint64_t)slot * kRecWords);
                 u32x4 ha = hq[0], hb = hq[1];
                 t_pin(ha); t_pin(hb);
                 bool have_mat;
@@ -614,11 +621,6 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
     if (tid < kListBins) bins[tid] = 0;
     __syncthreads();
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(new_kind);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(pool.kind + base);
-        for (uint32_t i = tid; i < (uint32_t)S / 4; i += kBlock) dst[i] = src[i] & 0x0F0F0F0Fu;
-    }
     // The segment's ray list, longest expected traversal first (counting sort, 16 classes): the stragglers of
     // the trace pass then start early instead of keeping a few lanes busy after the list has run dry.
     uint32_t my_key[S / kBlock];
@@ -645,7 +647,11 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++)
-        if (my_key[i] < kListBins) pool.list[base + atomicAdd(&bins[my_key[i]], 1u)] = (uint16_t)((uint32_t)(i * kBlock) + tid);
+        if (my_key[i] < kListBins) {
+            const uint32_t pos = base + atomicAdd(&bins[my_key[i]], 1u);
+            pool.list[pos] = (uint16_t)((uint32_t)(i * kBlock) + tid);
+            pool.kind[pos] = (uint8_t)SK_TRACE;                       // until the trace pass has been there
+        }
     if (STATS) cnt.flush_wave(a.stats);
     SP_MARK(7);                                                      // 7: kinds written back, ray list built
     SP_FLUSH();
@@ -678,6 +684,7 @@ struct TLane {
     double stash_ix, stash_iz;   // 1/d.x, 1/d.z of the frame a RotateY was entered from (they change only there) ...
     uint32_t stash_level;        // ... and that frame's mover depth (0xFFFFFFFF: nothing stashed)
     uint32_t slot;
+    uint32_t entry;        // where on the ray list the slot was found (its kind goes back to the same place)
     uint32_t steps;        // node steps of this ray
     int sp;
     uint32_t top, op;
@@ -815,7 +822,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
     if (probe) t_start = wall_clock64();
 
     TLane L;
-    L.has_ray = false; L.plain = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.steps = 0;
+    L.has_ray = false; L.plain = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
     L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
@@ -1137,7 +1144,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
                     pv.store_hit(slot, L.closest, L.win_leaf, L.win_face | (L.win_chain.n << 4) | steps16, L.win_chain, L.win_mat);
                     kind = L.win_mat >> kMatKindShift;                // (the word came with the winning primitive's record)
                 }
-                pool.kind[slot] = (uint8_t)kind;
+                pool.kind[L.entry] = (uint8_t)kind;                   // (by list position: see wf_shade)
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
@@ -1173,6 +1180,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
             if (probe && !dry_seen && drained) { dry_seen = true; t_dry = wall_clock64(); }
             if (entry_idx != 0xFFFFFFFFu) {
                 const uint32_t sbase = entry_idx & ~((uint32_t)S - 1u);
+                L.entry = entry_idx;
                 L.slot = sbase + pool.list[entry_idx];
                 uint64_t rs;
                 Ray wr = pv.load_ray(L.slot, rs);
@@ -1219,9 +1227,14 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
 
 // Marks the first `used` slots of every workgroup FRESH and the rest IDLE: a small job is spread
 // over all workgroups (a few slots each) instead of filling a few workgroups to the brim.
-__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint32_t n_slots, uint32_t used) {
+__global__ void __launch_bounds__(256) wf_init(uint8_t *kind, uint16_t *list, uint32_t *list_n, uint32_t n_slots, uint32_t used) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_slots) kind[i] = (i % (uint32_t)S) < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE;
+    if (i < n_slots) {                                            // the first "ray list" of a segment: its slots in use, all FRESH
+        const uint32_t local = i % (uint32_t)S;
+        kind[i] = local < used ? (uint8_t)SK_FRESH : (uint8_t)SK_IDLE;
+        list[i] = (uint16_t)local;
+        if (local == 0) list_n[i / (uint32_t)S] = used;
+    }
 }
 
 // ---- host side of the engine -------------------------------------------------------------
@@ -1300,7 +1313,7 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         uint32_t used = (uint32_t)(per_block > (uint64_t)S ? (uint64_t)S : (per_block + 63) / 64 * 64);
         if (used < 64) used = 64;
         uint32_t n = blocks * (uint32_t)S;
-        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, n, used);
+        hipLaunchKernelGGL(wf_init, dim3((n + 255) / 256), dim3(256), 0, stream, pool.kind, pool.list, pool.list_n, n, used);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.max_list, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
@@ -1320,7 +1333,7 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         const uint64_t off = (uint64_t)seg_begin * S;
         WfPool v = pool;
         v.n_blocks = n_segs; v.n_slots = n_segs * (uint32_t)S;
-        v.kind += off; v.ray += off * 8; v.hit += off * 8; v.state += off * 8; v.pixel_sum += off * 4;
+        v.kind += off; v.ray += off * kRecDoubles; v.hit += off * kRecWords; v.state += off * kRecWords; v.pixel_sum += off * 4;
         v.tape += off * pool.tape_cap * 4; v.list += off; v.list_n += seg_begin;
         v.n_active = pool.n_active + 2 * g;
         v.next_chunk = pool.next_chunk + g;

@@ -343,9 +343,9 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.n_slots = slots;
     q.n_blocks = blocks;
     q.kind = pool_alloc<uint8_t>(w, P);
-    q.ray = pool_alloc<double>(w, 8 * P);
-    q.hit = pool_alloc<uint32_t>(w, 8 * P);
-    q.state = pool_alloc<uint32_t>(w, 8 * P);
+    q.ray = pool_alloc<double>(w, kRecDoubles * P);                       // the 128-byte slot records: ray | hit | state
+    q.hit = reinterpret_cast<uint32_t *>(q.ray) + 16;
+    q.state = reinterpret_cast<uint32_t *>(q.ray) + 24;
     q.pixel_sum = pool_alloc<double>(w, 4 * P);
     q.tape = pool_alloc<double>(w, (uint64_t)depth * 4 * P);
     q.tape_cap = depth;
