@@ -773,9 +773,9 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
 } // namespace
 
 // Resident traversal workgroups per CU a variant is built and launched for (= waves per SIMD = its VGPR budget):
-// the sphere-only kernel needs 80 VGPRs and runs six (C2: +4.5 % over four), the full kernels four.
+// the sphere-only kernel needs 82 VGPRs and runs five (C2: +4 % over four; six would spill), the full kernels four.
 constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
-    return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? 6 : kTraceBlocksPerCU;
+    return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? 5 : kTraceBlocksPerCU;
 }
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
@@ -830,9 +830,9 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
     L.stash_ix = 0.0; L.stash_iz = 0.0; L.stash_level = 0xFFFFFFFFu;
     const int node_quorum = (int)(node_quorum_u & 0xFFu);
 #ifndef RT2022_SPHERE_REPS
-#define RT2022_SPHERE_REPS 3
+#define RT2022_SPHERE_REPS 2
 #endif
-    constexpr int sphere_reps = RT2022_SPHERE_REPS;                   // (a span-2 leaf pair and its neighbour in one turn: 3 measured +0.5 % over 2)
+    constexpr int sphere_reps = RT2022_SPHERE_REPS;                   // (a span-2 leaf pair in one turn; three: -1.6 % on the headline, -3 % on C2 in one A/B call)
     constexpr int tail_factor = 2;
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -9,7 +9,8 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 800
 spp = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 param = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-s = rt.HostScene(name, seed=2022, param=param)
+assets = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'assets')
+s = rt.HostScene(name, seed=2022, param=param, assets_dir=assets if os.path.isdir(assets) else None)
 cam, bg = s.default_view(W / H)
 rows = np.arange(H, dtype=np.uint32)
 dev = rt.DeviceScene(s.desc)
