@@ -410,6 +410,16 @@ def main():
                 if "wf_shade" in pmc:
                     r2, w2 = hbm_bytes(pmc["wf_shade"])
                     roof["traffic_per_step"]["wf_shade"] = int(r2 + w2)
+                    roof["traffic_per_step"]["wf_shade_read"] = int(r2)
+                    roof["traffic_per_step"]["wf_shade_write"] = int(w2)
+                # Calibration of this access pattern (profiles/r2_traffic_calibration.txt, tools/traffic_calib.sh): a lane's
+                # 64-byte ray fetch from a random 128-byte record is one 64-byte request and FETCH_SIZE reads it exactly
+                # (ratio 1.000); only whole-line requests are counted at half. wf_trace's reads are of the first kind, so
+                # the prescribed x2 doubles them: the calibrated figure takes FETCH_SIZE as it is.
+                roof["traffic_calibrated"] = {"wf_trace_per_launch": int((rd / 2.0 + wr) / launches), "wf_trace_per_step": int(rd / 2.0 + wr),
+                                              "bytes_per_ray": rnd((rd / 2.0 + wr) / max(counts["rays"], 1), 1),
+                                              "note": "reads = FETCH_SIZE x 1 (64-byte requests, measured ratio 1.000), writes = WRITE_SIZE (ratio 1.000); "
+                                                      "`traffic` above keeps the guide's x2 and is an upper bound"}
                 hb = gbs(rd + wr, tr_ms)
                 roof["hbm_counter"] = {"achieved": rnd(hb), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(hb, HBM_PEAK_GBS),
                                        "bytes_per_ray": rnd((rd + wr) / max(counts["rays"], 1), 1),

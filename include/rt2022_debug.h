@@ -43,6 +43,12 @@ int rt_debug_census(const rt_scene *scene, uint64_t rounds[9], uint64_t lanes[9]
  * to last wave end), mean wave lifetime, mean wave time after the workgroup's ray list ran dry}, then
  * {passes, waves}. lifetime / span = how evenly the waves finish; dry / lifetime = the under-filled tail. */
 int rt_debug_pass_timing(const rt_scene *scene, double out[5]);
+/* HBM counter calibration: moves a known number of bytes in the path pool's access patterns over a buffer of
+ * buffer_bytes (use several GiB: far beyond the Infinity Cache). mode 0 streaming read (16 B per lane, the whole
+ * buffer), 1 the first 64 B of n_access random 128-byte records, 2 whole random records, 3 streaming write,
+ * 4 32 B written at +64 of random records, 5 64 + 32 B written per random record, 6 single bytes at random places.
+ * Run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/traffic_calib.sh). */
+int rt_debug_traffic_probe(int mode, uint64_t buffer_bytes, uint64_t n_access, uint64_t seed);
 /* Traversal-stack entries the scene needs and the persistent grid size used for it. */
 int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
 

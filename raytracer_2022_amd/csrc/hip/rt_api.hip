@@ -873,6 +873,77 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
     });
 }
 
+} // extern "C"
+
+// ---- HBM counter calibration (tools/traffic_calib.sh) -------------------------------------------------------------
+// MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are calibrated for wide streaming accesses only ("calibrate on a known
+// byte count in your own access pattern before trusting an absolute"). These kernels move a KNOWN number of bytes in
+// the path pool's patterns — a 128-byte record per slot, slots visited in random order over a buffer far larger than
+// the 256 MiB Infinity Cache — so that the counters read under rocprofv3 can be set against them.
+namespace {
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint64_t probe_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+// MODE 0: streaming read, 16 B per lane; 1: 64 B (first half) of a random record; 2: all 128 B of a random record;
+// 3: streaming write; 4: 32 B written at +64 of a random record (a winner); 5: 64 + 32 B written (ray + bookkeeping);
+// 6: one byte written at a random position (the old per-slot kind array).
+template <int MODE>
+__global__ void __launch_bounds__(256) traffic_probe_kernel(probe_u32x4 *buf, uint64_t n_records, uint64_t n_access, uint64_t seed, uint32_t *sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    probe_u32x4 acc = {0u, 0u, 0u, 0u};
+    for (uint64_t i = gid; i < n_access; i += stride) {
+        if (MODE == 0) { acc += buf[i]; continue; }
+        if (MODE == 3) { buf[i] = (probe_u32x4){(uint32_t)i, 1u, 2u, 3u}; continue; }
+        const uint64_t rec = probe_mix(i ^ seed) % n_records;
+        probe_u32x4 *r = buf + rec * 8;                              // 128-byte record = 8 x 16 B
+        if (MODE == 1) { acc += r[0]; acc += r[1]; acc += r[2]; acc += r[3]; }
+        if (MODE == 2) { for (int k = 0; k < 8; k++) acc += r[k]; }
+        if (MODE == 4) { r[4] = (probe_u32x4){(uint32_t)i, 1u, 2u, 3u}; r[5] = (probe_u32x4){4u, 5u, 6u, 7u}; }
+        if (MODE == 5) { for (int k = 0; k < 4; k++) r[k] = (probe_u32x4){(uint32_t)i, (uint32_t)k, 2u, 3u}; r[6] = (probe_u32x4){1u, 1u, 1u, 1u}; r[7] = (probe_u32x4){2u, 2u, 2u, 2u}; }
+        if (MODE == 6) { reinterpret_cast<uint8_t *>(buf)[probe_mix(i ^ seed ^ 0x5555) % (n_records * 128)] = (uint8_t)i; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) *sink = acc.x;      // (keeps the loads alive)
+}
+template <int MODE>
+void launch_probe(probe_u32x4 *buf, uint64_t n_records, uint64_t n_access, uint64_t seed, uint32_t *sink) {
+    hipLaunchKernelGGL((traffic_probe_kernel<MODE>), dim3(256 * 16), dim3(256), 0, nullptr, buf, n_records, n_access, seed, sink);
+}
+} // namespace
+
+extern "C" {
+
+int rt_debug_traffic_probe(int mode, uint64_t buffer_bytes, uint64_t n_access, uint64_t seed) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(mode >= 0 && mode <= 6 && buffer_bytes >= 4096, RT_ERR_INVALID, "rt_debug_traffic_probe: bad arguments");
+        probe_u32x4 *buf = nullptr;
+        uint32_t *sink = nullptr;
+        int rc = RT_OK;
+        try {
+            RT_HIP(hipMalloc((void **)&buf, buffer_bytes));
+            RT_HIP(hipMalloc((void **)&sink, 4));
+            RT_HIP(hipMemset(buf, 1, buffer_bytes));
+            RT_HIP(hipDeviceSynchronize());
+            const uint64_t n_records = buffer_bytes / 128;
+            if (mode == 0 || mode == 3) n_access = buffer_bytes / 16;
+            switch (mode) {
+                case 0: launch_probe<0>(buf, n_records, n_access, seed, sink); break;
+                case 1: launch_probe<1>(buf, n_records, n_access, seed, sink); break;
+                case 2: launch_probe<2>(buf, n_records, n_access, seed, sink); break;
+                case 3: launch_probe<3>(buf, n_records, n_access, seed, sink); break;
+                case 4: launch_probe<4>(buf, n_records, n_access, seed, sink); break;
+                case 5: launch_probe<5>(buf, n_records, n_access, seed, sink); break;
+                default: launch_probe<6>(buf, n_records, n_access, seed, sink); break;
+            }
+            RT_HIP(hipGetLastError());
+            RT_HIP(hipDeviceSynchronize());
+        } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
+        if (buf) (void)hipFree(buf);
+        if (sink) (void)hipFree(sink);
+        return rc;
+    });
+}
+
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
