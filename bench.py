@@ -301,11 +301,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT2022_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards,
+    # collectives go over gloo on host copies). Never a measurement: the line says so.
+    backend = os.environ.get("RT2022_BENCH_BACKEND", "nccl")
+    rehearsal = world > 1 and backend != "nccl"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    coll = (lambda t: t.cpu()) if rehearsal else (lambda t: t)       # what a collective is handed
 
     assets = args.assets if os.path.isdir(args.assets) else None
     scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
@@ -321,7 +330,7 @@ def main():
     # (strong scaling deals H rows over `world` ranks: the shares differ by at most one row; gather needs equal shapes)
     max_rows = -(-H * n_frames // world)
     d_pad = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev) if max_rows != n_rows else None
-    gather_list = [torch.empty((max_rows, W, 3), dtype=torch.float64, device=dev) for _ in range(world)] \
+    gather_list = [torch.empty((max_rows, W, 3), dtype=torch.float64, device="cpu" if rehearsal else dev) for _ in range(world)] \
         if (world > 1 and rank == 0 and not args.no_gather) else None
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -337,7 +346,7 @@ def main():
             if d_pad is not None:
                 d_pad[:n_rows].copy_(d_out)
                 src = d_pad
-            dist.gather(src, gather_list, dst=0)
+            dist.gather(coll(src), gather_list, dst=0)
 
     # Counter pass (untimed, deterministic): rays / node visits / primitive tests of one step.
     pc = F.rt_params.from_buffer_copy(params)
@@ -363,6 +372,7 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     cnt = torch.tensor([counts["rays"], counts["paths"]], dtype=torch.float64, device=dev)
     if world > 1:
+        t, cnt = coll(t), coll(cnt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -481,7 +491,8 @@ def main():
                       else "Mrays/s (primary+secondary)",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_frame": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearsal else
+            "synthetic — REHEARSAL over %s with ranks sharing GPUs: not a measurement" % backend,
             "config": {"workload": desc_text if args.spp == 0 else desc_text + " [spp overridden to %d]" % spp,
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "max_depth": 50,
                        "frames": n_frames, "rows_per_gpu": n_rows, "spp_chunk": int(s.spp_chunk) if kernel_ms else args.spp_chunk,
