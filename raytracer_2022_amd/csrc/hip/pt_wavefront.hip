@@ -692,11 +692,11 @@ struct TLane {
     bool plain;            // the fast node step applies to this ray (see there)
 };
 
-template <int STACK>
+template <int STACK, int WG = kBlock>
 struct TStack {
     uint32_t *col;
-    RT_DEV void push(TLane &L, uint32_t ref) { if (L.sp < STACK) { col[L.sp * kBlock] = ref; L.sp++; } }
-    RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * kBlock]; } return REF_EMPTY; }
+    RT_DEV void push(TLane &L, uint32_t ref) { if (L.sp < STACK) { col[L.sp * WG] = ref; L.sp++; } }
+    RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * WG]; } return REF_EMPTY; }
 };
 
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
@@ -735,8 +735,8 @@ RT_DEV bool t_box(double p0x, double p0y, double p0z, double p1x, double p1y, do
 // L.top has just been set: label it. The two cheap steps of ConstantMedium::hit — start the first
 // boundary query, turn the first into the second (constantmedium.rs:50-51) — are taken on the spot
 // instead of costing the wave a scheduling round each; only the finish (RNG, log) is an operation.
-template <int STACK, bool STATS, unsigned FEAT>
-RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_min, Counters<STATS> &cnt) {
+template <int STACK, bool STATS, unsigned FEAT, int WG>
+RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK, WG> &st, double t_min, Counters<STATS> &cnt) {
     if (FEAT & kFeatVolumes) {
         for (int guard = 0; guard < 6; guard++) {
             if (RT_REF_KIND(L.top) == RT_KIND_MEDIUM) {               // a medium leaf: boundary.hit(r, -inf, inf)
@@ -767,8 +767,8 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
     }
     L.op = classify(L.top);
 }
-#define T_NEXT() do { L.top = st.pop(L); t_settle<STACK, STATS, FEAT>(s, L, st, t_min, cnt); } while (0)
-#define T_SETTLE() t_settle<STACK, STATS, FEAT>(s, L, st, t_min, cnt)
+#define T_NEXT() do { L.top = st.pop(L); t_settle<STACK, STATS, FEAT, WG>(s, L, st, t_min, cnt); } while (0)
+#define T_SETTLE() t_settle<STACK, STATS, FEAT, WG>(s, L, st, t_min, cnt)
 
 } // namespace
 
@@ -777,25 +777,47 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK> &st, double t_mi
 constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
     return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? 5 : kTraceBlocksPerCU;
 }
+// The node-cache variant (WG = kCacheBlock threads, one workgroup per CU, CACHE = kNodeCache records): the BVH's first
+// CACHE node records live in LDS — 48 bytes of box and 8 of child refs each — beside the traversal stacks of the
+// workgroup's 16 waves. A node step on a cached node is an LDS round trip instead of an L1 / L2 one; the 160 KiB of a
+// CU belong to ONE workgroup, so the table exists once per CU rather than once per four waves. Every other node is
+// fetched from HBM exactly as in the plain kernels: same records, same arithmetic, same results.
+constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg) {
+    return wg == kBlock ? trace_blocks_per_cu(stack, stats, feat) : wg / 256;
+}
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
-template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
-__global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT)) wf_trace(const SceneDev s, const WfPool pool,
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0>
+__global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, WG)) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
-    __shared__ uint32_t stack_lds[STACK * kBlock];
+    __shared__ uint32_t stack_lds[STACK * WG];
     // The world ray of every lane's current path, [component][lane] (12 KiB where the scene has movers, 48 bytes
     // otherwise): leaving a mover restarts from it (a ray_at_level of the enclosing frame) without going back to HBM.
     // (The deeper-stack variants have no LDS to spare at four workgroups per CU: they fetch it from the pool again.)
-    constexpr bool kStash = (FEAT & kFeatMovers) != 0 && STACK <= kStackSmall;
-    __shared__ double wray_lds[kStash ? 6 * kBlock : 6];
+    constexpr bool kStash = (FEAT & kFeatMovers) != 0 && STACK <= kStackSmall && CACHE == 0;
+    __shared__ double wray_lds[kStash ? 6 * WG : 6];
+    // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node.
+    __shared__ f64x2 nc_box[CACHE > 0 ? 3 * CACHE : 1];
+    __shared__ uint2 nc_ref[CACHE > 0 ? CACHE : 1];
     const PoolView pv{pool};
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
-    TStack<STACK> st{stack_lds + tid};
+    TStack<STACK, WG> st{stack_lds + tid};
+    const uint32_t n_cached = CACHE > 0 ? (s.n_nodes < (uint32_t)CACHE ? s.n_nodes : (uint32_t)CACHE) : 0u;
+    if (CACHE > 0) {
+        for (uint32_t i = tid; i < n_cached; i += (uint32_t)WG) {
+            const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + i);
+            f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
+            const uint2 rr = reinterpret_cast<const uint2 *>(np)[6];
+            nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
+            nc_ref[i] = rr;
+        }
+        __syncthreads();
+    }
     double *const wray = wray_lds + (kStash ? tid : 0u);
 
     // Work of a pass = the ray lists of all segments (written by the preceding shade pass), cut into chunks of
@@ -813,7 +835,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
     // every access is a real ds_read_b128 / ds_write_b128 in program order — one wave's LDS operations complete in
     // the order it issues them, and the compiler may not carry the words in registers from one round to the next.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ u32x4 chunk_lds[kBlock / 64];
+    __shared__ u32x4 chunk_lds[WG / 64];
     volatile u32x4 *const cs = &chunk_lds[tid >> 6];
     if (lane == 0) *cs = (u32x4){0u, 0u, 0u, 0u};
     const bool probe = PROBE && pool.dbg != nullptr;                  // (rt_debug_pass_timing: a build of its own, all arms)
@@ -865,13 +887,24 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
                 // requested together, before the arithmetic — no load waits for the outcome of the test.
                 cnt.node();
                 L.steps++;
-                const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + RT_REF_INDEX(L.top));
-                uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                const uint32_t nidx = RT_REF_INDEX(L.top);
                 const int below_sp = L.sp > 0 ? L.sp - 1 : 0;
-                const uint32_t below = st.col[below_sp * kBlock];
-                double bmin[3] = {rtm::u2d(((uint64_t)q0.y << 32) | q0.x), rtm::u2d(((uint64_t)q0.w << 32) | q0.z), rtm::u2d(((uint64_t)q1.y << 32) | q1.x)};
-                double bmax[3] = {rtm::u2d(((uint64_t)q1.w << 32) | q1.z), rtm::u2d(((uint64_t)q2.y << 32) | q2.x), rtm::u2d(((uint64_t)q2.w << 32) | q2.z)};
-                const uint32_t left = q3.x, right = q3.y;
+                double bmin[3], bmax[3];
+                uint32_t left, right, below;
+                if (CACHE > 0 && nidx < n_cached) {
+                    const f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
+                    const uint2 cr = nc_ref[nidx];
+                    below = st.col[below_sp * WG];
+                    bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
+                    left = cr.x; right = cr.y;
+                } else {
+                    const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + nidx);
+                    uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    below = st.col[below_sp * WG];
+                    bmin[0] = rtm::u2d(((uint64_t)q0.y << 32) | q0.x); bmin[1] = rtm::u2d(((uint64_t)q0.w << 32) | q0.z); bmin[2] = rtm::u2d(((uint64_t)q1.y << 32) | q1.x);
+                    bmax[0] = rtm::u2d(((uint64_t)q1.w << 32) | q1.z); bmax[1] = rtm::u2d(((uint64_t)q2.y << 32) | q2.x); bmax[2] = rtm::u2d(((uint64_t)q2.w << 32) | q2.z);
+                    left = q3.x; right = q3.y;
+                }
                 double tmn = L.t_lo, tmx = t_hi(L);
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
@@ -888,7 +921,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
                 const uint32_t lk = RT_REF_KIND(left);
                 const bool twin = left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING;
                 const bool push = hit && !twin && L.sp < STACK;
-                if (push) st.col[L.sp * kBlock] = right;
+                if (push) st.col[L.sp * WG] = right;
                 if (STATS && hit && twin) cnt.prim(lk);
                 const uint32_t next = hit ? left : (L.sp > 0 ? below : REF_EMPTY);
                 L.sp = hit ? L.sp + (push ? 1 : 0) : below_sp;
@@ -917,9 +950,18 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
         } else if (best == OP_NODE) {
             cnt.node();
             L.steps++;
-            const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + RT_REF_INDEX(L.top));
-            f64x2 n0 = np[0], n1 = np[1], n2 = np[2];
-            u32x4 n3 = reinterpret_cast<const u32x4 *>(np)[3];
+            const uint32_t nidx = RT_REF_INDEX(L.top);
+            f64x2 n0, n1, n2;
+            u32x4 n3;
+            if (CACHE > 0 && nidx < n_cached) {
+                n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
+                const uint2 cr = nc_ref[nidx];
+                n3 = (u32x4){cr.x, cr.y, 0u, 0u};
+            } else {
+                const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + nidx);
+                n0 = np[0]; n1 = np[1]; n2 = np[2];
+                n3 = reinterpret_cast<const u32x4 *>(np)[3];
+            }
             t_pin(n0); t_pin(n1); t_pin(n2); t_pin(n3);
             const double bmin[3] = {n0.x, n0.y, n1.x}, bmax[3] = {n1.y, n2.x, n2.y};
             double tmn = L.t_lo, tmx = t_hi(L);
@@ -1088,7 +1130,7 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
                 // the world ray from this lane's LDS column (written at refill), then back down to the enclosing frame
                 XRay world;
                 if (kStash) {
-                    world = XRay{Vec3(wray[0 * kBlock], wray[1 * kBlock], wray[2 * kBlock]), Vec3(wray[3 * kBlock], wray[4 * kBlock], wray[5 * kBlock])};
+                    world = XRay{Vec3(wray[0 * WG], wray[1 * WG], wray[2 * WG]), Vec3(wray[3 * WG], wray[4 * WG], wray[5 * WG])};
                 } else {
                     Ray wr = pv.load_ray(L.slot);
                     world = XRay{wr.orig, wr.dir};
@@ -1192,8 +1234,8 @@ __global__ void __launch_bounds__(kBlock, trace_blocks_per_cu(STACK, STATS, FEAT
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
                 if (FEAT & kFeatMovers) L.stash_level = 0xFFFFFFFFu;
                 if (kStash) {                                         // what leaving a mover goes back to (OP_CTX)
-                    wray[0 * kBlock] = wr.orig.x; wray[1 * kBlock] = wr.orig.y; wray[2 * kBlock] = wr.orig.z;
-                    wray[3 * kBlock] = wr.dir.x; wray[4 * kBlock] = wr.dir.y; wray[5 * kBlock] = wr.dir.z;
+                    wray[0 * WG] = wr.orig.x; wray[1 * WG] = wr.orig.y; wray[2 * WG] = wr.orig.z;
+                    wray[3 * WG] = wr.dir.x; wray[4 * WG] = wr.dir.y; wray[5 * WG] = wr.dir.z;
                 }
                 L.closest = rtm::F64_MAX;
                 L.steps = 0;
@@ -1267,6 +1309,33 @@ static void launch_trace(const WfLaunch &w, uint32_t parity) {
     hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(grid), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
                        w.node_quorum, parity, w.stats);
 }
+// The node-cache variant: one workgroup of kCacheBlock threads per CU (see wf_trace).
+template <unsigned FEAT>
+static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
+    uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
+    const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
+    if (grid > most) grid = most;
+    hipLaunchKernelGGL((wf_trace<kStackTiny, false, FEAT, false, kCacheBlock, kNodeCache>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
+                       w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats);
+}
+static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
+    switch (feat & 7u) {
+        case 0: launch_trace_cached<0>(w, parity); break;
+        case 1: launch_trace_cached<1>(w, parity); break;
+        case 2: launch_trace_cached<2>(w, parity); break;
+        case 3: launch_trace_cached<3>(w, parity); break;
+        case 4: launch_trace_cached<4>(w, parity); break;
+        case 5: launch_trace_cached<5>(w, parity); break;
+        case 6: launch_trace_cached<6>(w, parity); break;
+        default: launch_trace_cached<7>(w, parity); break;
+    }
+}
+// Whether a scene takes the node-cache variant: its stacks fit the variant's, and its node table fits the cache whole.
+// (RT2022_NODE_CACHE=0 in the environment keeps the plain kernels: A/B runs.)
+static bool use_node_cache(const WfLaunch &w, uint32_t stack_need) {
+    static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
+    return enabled && stack_need <= (uint32_t)kStackTiny && w.scene.n_nodes <= (uint32_t)kNodeCache;
+}
 template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
     switch (feat & 7u) {
@@ -1285,7 +1354,9 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (between) (void)hipEventRecord(between, w.stream);
-    if (stack_need <= (uint32_t)kStackSmall) {
+    if (!counters && !probe && use_node_cache(w, stack_need)) {
+        launch_trace_cached_feat(features, w, parity);
+    } else if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
         else if (probe) launch_trace_feat<kStackSmall, true>(features, w, parity);   // (the probe exists per feature set for the small stack only)
         else launch_trace_feat<kStackSmall>(features, w, parity);

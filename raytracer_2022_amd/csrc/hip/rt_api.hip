@@ -626,6 +626,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.perlins = upload(desc->perlins, desc->n_perlins, sc->owned);
             s.root = desc->root;
             s.n_lights = desc->n_lights;
+            s.n_nodes = desc->n_nodes;
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
             sc->boxes_plain = v.boxes_plain();
