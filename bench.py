@@ -57,6 +57,8 @@ BYTES_PIXEL = 24
 # Peaks, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0      # HBM3E, spec (6 290 measured by a float4 copy)
 L2_PEAK_GBS = 34500.0      # aggregate of the eight 4 MiB L2s
+LDS_PEAK_GBS = 256 * 256 * 2.4  # 256 CUs x 256 B per clock (conflict-free ds_read_b128) x 2.4 GHz = 157 TB/s
+BYTES_NODE_LDS = 56        # what a node step reads from the LDS node table: 48 B of box + 8 B of child refs
 FP64_VECTOR_TFLOPS = 78.6  # = 39.3 T f64 lane-instructions/s (an FMA counts two flops)
 N_SIMDS = 256 * 4
 L2_BYTES = 32 << 20
@@ -391,6 +393,11 @@ def main():
         frac = lambda x, peak: None if x is None else round(x / peak, 4)
         achieved = gbs(ab["wf_trace"], tr_ms)
         sbytes = scene_bytes(scene.desc)
+        # Which traversal variant ran: with the node table in LDS the node bytes never reach L1 / L2 (primitives still do).
+        tv = dscene.trace_variant()
+        nodes_in_lds = tv["nodes_in_lds"] >= scene.desc.n_nodes and tv["nodes_in_lds"] > 0
+        lds_bytes = BYTES_NODE_LDS * counts["node_visits"] if nodes_in_lds else 0
+        cache_bytes = ab["traversal"] - (BYTES_NODE * counts["node_visits"] if nodes_in_lds else 0)
 
         roof = {
             "bound": "hbm", "kernel": "wf_trace (BVH traversal + Hittable::hit, pt_wavefront.hip): %.0f %% of the frame's device time" % (100.0 * tr_ms / k_ms if k_ms else 0),
@@ -404,9 +411,11 @@ def main():
             "traversal_only": {"bytes": int(ab["traversal"]), "achieved": rnd(gbs(ab["traversal"], tr_ms)),
                                "frac": frac(gbs(ab["traversal"], tr_ms), HBM_PEAK_GBS)},
             # the same traversal bytes against the level that really serves them when the scene fits in cache
-            "l2": {"achieved": rnd(gbs(ab["traversal"], tr_ms)), "peak": L2_PEAK_GBS, "unit": "GB/s",
-                   "frac": frac(gbs(ab["traversal"], tr_ms), L2_PEAK_GBS),
+            "l2": {"achieved": rnd(gbs(cache_bytes, tr_ms)), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                   "frac": frac(gbs(cache_bytes, tr_ms), L2_PEAK_GBS), "bytes_per_step": int(cache_bytes),
+                   "what": "primitive records (the node records are read from LDS)" if nodes_in_lds else "node and primitive records",
                    "scene_bytes": int(sbytes), "fits_aggregate_l2": bool(sbytes <= L2_BYTES)},
+            "trace_variant": tv,
             "pmc": pmc_note,
         }
         limiter = []
@@ -473,14 +482,23 @@ def main():
                     roof["traffic_source"] = "committed profile %s (not measured by this run: %s)" % (src, pmc_note)
         if roof["l2"]["frac"] is not None and roof["l2"]["fits_aggregate_l2"]:
             limiter.append(("l2", roof["l2"]["frac"]))
+        if nodes_in_lds:
+            roof["lds"] = {"achieved": rnd(gbs(lds_bytes, tr_ms)), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s", "frac": frac(gbs(lds_bytes, tr_ms), LDS_PEAK_GBS),
+                           "bytes_per_step": int(lds_bytes),
+                           "what": "%d B per node visit from the workgroup's node table (3 x ds_read_b128 + ds_read_b64 at random records: bank conflicts "
+                                   "make the usable rate a third to a quarter of the conflict-free peak)" % BYTES_NODE_LDS}
+            limiter.append(("lds", roof["lds"]["frac"]))
         if limiter:
             limiter.sort(key=lambda kv: -(kv[1] or 0))
             roof["limiter"] = {"resource": limiter[0][0], "frac": limiter[0][1], "ranked": limiter,
                                "note": "bound = the contractual roofline of SURVEY.md §8(d); limiter = the resource the counters of this run show closest to its ceiling"}
         note = ["scene %.2f MB (%s the 32 MiB of aggregate L2)" % (sbytes / 1e6, "fits" if sbytes <= L2_BYTES else "exceeds")]
+        if nodes_in_lds:
+            note.append("traversal variant: %d-thread workgroups, all %d node records in LDS" % (tv["workgroup_threads"], tv["nodes_in_lds"]))
         if roof.get("hbm_counter"):
             note.append("measured HBM traffic of wf_trace %.0f B per ray segment = %.2f of the 8 TB/s peak, against an algorithmic fraction of %.2f: "
-                        "the node and primitive bytes are served by the caches" % (roof["hbm_counter"]["bytes_per_ray"], roof["hbm_counter"]["frac"], roof["frac"] or 0))
+                        "the node and primitive bytes are served by %s" % (roof["hbm_counter"]["bytes_per_ray"], roof["hbm_counter"]["frac"], roof["frac"] or 0,
+                                                                          "LDS and the caches" if nodes_in_lds else "the caches"))
         if roof.get("valu"):
             note.append("wf_trace issues %.2f of the chip's VALU slots at %.0f %% lane utilisation and its waves wait %.0f %% of their cycles"
                         % (roof["valu"]["issue_busy"], 100 * (roof["valu"]["lane_utilisation"] or 0), 100 * (roof["valu"]["wait_any_over_wave_cycles"] or 0)))

@@ -159,7 +159,7 @@ ABI_SYMBOLS = [
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
     "rtb_last_error", "rtb_abi_sizes",
-    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe",
+    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe",
 ]
 
 _lib = None
@@ -208,6 +208,7 @@ def lib():
     L.rt_debug_math_device.argtypes = [C.c_int, P(dbl), P(dbl), P(dbl), u64]
     L.rt_debug_rng_device.argtypes = [u64, C.c_int, dbl, dbl, u64, P(u64), u64]
     L.rt_debug_scene_info.argtypes = [vp, P(u32), P(i32)]
+    L.rt_debug_trace_variant.argtypes = [vp, P(u32), P(u32), P(u32)]
     L.rt_debug_set_tuning.argtypes = [vp, u32, u32]
     L.rt_debug_set_engine.argtypes = [vp, C.c_int, C.c_int]
     L.rt_debug_census.argtypes = [vp, P(u64), P(u64)]

@@ -55,6 +55,8 @@ typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <class T>
 RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
+// The wave's vote as the hardware gives it (a v_cmp into an SGPR pair); HIP's __ballot materialises the predicate as 0 / 1 first.
+RT_DEV unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 struct PoolView {
     const WfPool &p;
@@ -273,8 +275,11 @@ RT_DEV Vec3 texture_value_top(const SceneDev &s, uint32_t tex, uint32_t tex_kind
 #define SP_FLUSH() do {} while (0)
 #endif
 
+#ifndef RT2022_SHADE_WAVES
+#define RT2022_SHADE_WAVES 3           // resident shade workgroups per CU = waves per SIMD (168 VGPRs; four: 128 VGPRs, 51 spilled)
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool, const uint32_t parity) {
+__global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool, const uint32_t parity) {
     __shared__ uint32_t hist[SK_COUNT];
     __shared__ uint32_t cursor[SK_COUNT];
     __shared__ uint32_t sorted[S];
@@ -496,7 +501,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
         // divisions) is the longest stretch of this kernel, and here it would run for the fifth of the lanes that need it.
         const bool want_path = on && (kind == SK_FRESH || ended);
         {
-            const unsigned long long wm = __ballot(want_path);
+            const unsigned long long wm = wballot(want_path);
             if (wm) {
                 const int leader = __ffsll((long long)wm) - 1;
                 uint32_t qbase = 0;
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__(kBlock, 3) wf_shade(const SceneDev s, const Re
                     }
                     have_item = false;
                 }
-                unsigned long long m = __ballot(need);
+                unsigned long long m = wballot(need);
                 if (m) {
                     int leader = __ffsll((long long)m) - 1;
                     unsigned long long wbase = 0;
@@ -863,13 +868,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         // Fast path: keep stepping nodes while enough lanes want to.
         for (;;) {
             bool isn = L.op == OP_NODE && L.plain;
-            int nn = __popcll(__ballot(isn));
+            int nn = __popcll(wballot(isn));
             if (nn < node_quorum) {
                 // Below the quorum the vote decides — except where its outcome is known: node steps weigh
                 // 1 and everything else 2 by default, so with nn > 2 x (all other pending lanes) the vote
                 // would pick the node step anyway (the usual case at the tail of a pass, when the list has
                 // run dry and a few long rays are left). Staying here saves the vote.
-                int others = __popcll(__ballot(!isn && L.op != OP_IDLE));
+                int others = __popcll(wballot(!isn && L.op != OP_IDLE));
                 if (nn == 0 || nn <= tail_factor * others) break;
             }
             if (STATS && lane == 0) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; }
@@ -892,9 +897,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
                 if (CACHE > 0 && nidx < n_cached) {
-                    const f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
-                    const uint2 cr = nc_ref[nidx];
+                    f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
+                    uint2 cr = nc_ref[nidx];
                     below = st.col[below_sp * WG];
+                    t_pin(c0); t_pin(c1); t_pin(c2); t_pin(cr.x); t_pin(cr.y); t_pin(below);      // (all five reads issued before the arithmetic: one wait)
                     bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
                     left = cr.x; right = cr.y;
                 } else {
@@ -936,13 +942,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (!(FEAT & kFeatMisc) && o == (int)OP_MISC) continue;
             if (!(FEAT & kFeatMovers) && o == (int)OP_CTX) continue;
             if (!(FEAT & kFeatVolumes) && (o == (int)OP_BOX || o == (int)OP_MEDIUM)) continue;
-            int n = __popcll(__ballot(L.op == (uint32_t)o));
+            int n = __popcll(wballot(L.op == (uint32_t)o));
             int score = o == (int)OP_NODE ? n : 2 * n;                // a node step outside the fast path yields to everything else (1.5x and 3x measured the same)
             if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
         if (STATS) {
-            unsigned served = (unsigned)__popcll(__ballot(L.op == (uint32_t)best));
+            unsigned served = (unsigned)__popcll(wballot(L.op == (uint32_t)best));
             if (lane == 0) { census_rounds[best]++; census_lanes[best] += served; }
         }
         if (L.op != (uint32_t)best) {
@@ -1193,7 +1199,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
                 L.has_ray = false;
             }
-            const unsigned long long m = __ballot(true);
+            const unsigned long long m = wballot(true);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t need = (uint32_t)__popcll(m);
             uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -1332,9 +1338,9 @@ static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t 
 }
 // Whether a scene takes the node-cache variant: its stacks fit the variant's, and its node table fits the cache whole.
 // (RT2022_NODE_CACHE=0 in the environment keeps the plain kernels: A/B runs.)
-static bool use_node_cache(const WfLaunch &w, uint32_t stack_need) {
+static bool use_node_cache(const SceneDev &scene, uint32_t stack_need) {
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
-    return enabled && stack_need <= (uint32_t)kStackTiny && w.scene.n_nodes <= (uint32_t)kNodeCache;
+    return enabled && stack_need <= (uint32_t)kStackTiny && scene.n_nodes <= (uint32_t)kNodeCache;
 }
 template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
@@ -1354,7 +1360,7 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (between) (void)hipEventRecord(between, w.stream);
-    if (!counters && !probe && use_node_cache(w, stack_need)) {
+    if (!counters && !probe && use_node_cache(w.scene, stack_need)) {
         launch_trace_cached_feat(features, w, parity);
     } else if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
@@ -1519,6 +1525,13 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
     }
     if (out_iterations) *out_iterations = iterations;
     return hipSuccess;
+}
+
+void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t out[3]) {
+    if (use_node_cache(scene, stack_need)) { out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes; return; }
+    out[0] = (uint32_t)kBlock;
+    out[1] = stack_need <= (uint32_t)kStackSmall ? (uint32_t)kStackSmall : stack_need <= (uint32_t)kStackMid ? (uint32_t)kStackMid : (uint32_t)kStackLarge;
+    out[2] = 0;
 }
 
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
