@@ -785,8 +785,8 @@ constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
 // The node-cache variant (WG = kCacheBlock threads, one workgroup per CU, CACHE = kNodeCache records): the BVH's first
 // CACHE node records live in LDS — 48 bytes of box and 8 of child refs each — beside the traversal stacks of the
 // workgroup's 16 waves. A node step on a cached node is an LDS round trip instead of an L1 / L2 one; the 160 KiB of a
-// CU belong to ONE workgroup, so the table exists once per CU rather than once per four waves. Every other node is
-// fetched from HBM exactly as in the plain kernels: same records, same arithmetic, same results.
+// CU belong to ONE workgroup, so the table exists once per CU rather than once per four waves. The variant is launched
+// only for scenes whose whole node table fits (use_node_cache); same records, same arithmetic, same results.
 constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg) {
     return wg == kBlock ? trace_blocks_per_cu(stack, stats, feat) : wg / 256;
 }
@@ -865,20 +865,23 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     for (;;) {
-        // Fast path: keep stepping nodes while enough lanes want to.
-        for (;;) {
+        // Fast path: keep stepping nodes while enough lanes want to — nn >= the quorum. Below the quorum the vote
+        // decides, except where its outcome is known: node steps weigh 1 and everything else 2, so with
+        // nn > 2 x (all other pending lanes) the vote would pick the node step anyway (the usual case at the tail of a
+        // pass, when the list has run dry and a few long rays are left); staying here saves the vote.
+        // Inside the loop a lane can only leave the node state (the others are parked), so the number of pending
+        // lanes is fixed on entry and both conditions are ONE threshold on nn: nn >= quorum, or 3 nn > 2 pending.
+        // The loop itself is a plain divergent loop over the node lanes — a lane that leaves the node state drops out
+        // of it, and all that are left go together when their count falls below the threshold.
+        {
             bool isn = L.op == OP_NODE && L.plain;
             int nn = __popcll(wballot(isn));
-            if (nn < node_quorum) {
-                // Below the quorum the vote decides — except where its outcome is known: node steps weigh
-                // 1 and everything else 2 by default, so with nn > 2 x (all other pending lanes) the vote
-                // would pick the node step anyway (the usual case at the tail of a pass, when the list has
-                // run dry and a few long rays are left). Staying here saves the vote.
-                int others = __popcll(wballot(!isn && L.op != OP_IDLE));
-                if (nn == 0 || nn <= tail_factor * others) break;
-            }
-            if (STATS && lane == 0) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; }
-            if (isn) {
+            const int pending = __popcll(wballot(L.op != OP_IDLE));
+            const int tail_threshold = tail_factor * pending / (tail_factor + 1) + 1;
+            const int threshold = node_quorum < tail_threshold ? node_quorum : tail_threshold;
+            if (isn && nn >= threshold) do {
+                if (STATS) { const unsigned long long am = wballot(true); if ((int)lane == __ffsll((long long)am) - 1) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; } }
+                {
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
                 // at once, the right one waits on the stack and is tested against the then-closest hit.
                 //
@@ -896,7 +899,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 const int below_sp = L.sp > 0 ? L.sp - 1 : 0;
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
-                if (CACHE > 0 && nidx < n_cached) {
+                if (CACHE > 0) {                                  // (this variant is launched only for scenes whose every node is in the table)
                     f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
                     uint2 cr = nc_ref[nidx];
                     below = st.col[below_sp * WG];
@@ -933,7 +936,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.sp = hit ? L.sp + (push ? 1 : 0) : below_sp;
                 L.top = next;
                 L.op = classify(next);                            // (media met here start in their own arm)
-            }
+                }
+                isn = L.op == OP_NODE;
+                nn = __popcll(wballot(isn));
+            } while (isn && nn >= threshold);
         }
         // Vote: the label most lanes are waiting on (ties -> lowest id).
         int best = -1, best_n = 0;
@@ -959,7 +965,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const uint32_t nidx = RT_REF_INDEX(L.top);
             f64x2 n0, n1, n2;
             u32x4 n3;
-            if (CACHE > 0 && nidx < n_cached) {
+            if (CACHE > 0) {                                  // (this variant is launched only for scenes whose every node is in the table)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const uint2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, cr.y, 0u, 0u};
@@ -1268,7 +1274,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     }
     if (STATS) {
         cnt.flush_wave(stats);
-        if (lane == 0 && stats)
+        if (stats)                                                // (each lane adds what it counted as a round's first lane)
             for (int o = 0; o < 9; o++) {
                 if (census_rounds[o]) atomicAdd(&stats->op_rounds[o], (unsigned long long)census_rounds[o]);
                 if (census_lanes[o]) atomicAdd(&stats->op_lanes[o], (unsigned long long)census_lanes[o]);
