@@ -680,7 +680,6 @@ struct TLane {
     double sub_closest;
     double med_t1;
     uint32_t med_ref;      // the medium being evaluated (0 = none: main query)
-    bool sub_found;
     Rng rng;
     Chain ctx;
     Chain win_chain;
@@ -693,8 +692,13 @@ struct TLane {
     uint32_t steps;        // node steps of this ray
     int sp;
     uint32_t top, op;
-    bool has_ray;
-    bool plain;            // the fast node step applies to this ray (see there)
+    // Per-lane flags in ONE register rather than three bools: a bool member lives as a lane mask in a scalar register
+    // pair, and every join of the scheduler's control flow then merges each of them with three scalar instructions
+    // (seen in the ISA: ~30 per round of the outer loop); a vector register needs no merging.
+    //   kPlain     the fast node step applies to this ray (see there)
+    //   kHasRay    the lane carries a ray
+    //   kSubFound  the medium sub-query in progress has found a boundary hit
+    uint32_t flags;
 };
 
 template <int STACK, int WG = kBlock>
@@ -704,11 +708,14 @@ struct TStack {
     RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * WG]; } return REF_EMPTY; }
 };
 
+constexpr uint32_t kPlain = 1u, kHasRay = 2u, kSubFound = 4u;
+RT_DEV void t_flag(TLane &L, uint32_t bit, bool on) { L.flags = on ? (L.flags | bit) : (L.flags & ~bit); asm volatile("" : "+v"(L.flags)); }
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
 // The fast node step applies (see there): every 1/d finite and non-zero, origin finite, boxes plain.
 RT_DEV void t_flags(TLane &L, bool boxes_plain) {
-    L.plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
+    const bool plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
               L.inv.z != 0.0 && t_finite(L.cur.o.x) && t_finite(L.cur.o.y) && t_finite(L.cur.o.z);
+    t_flag(L, kPlain, plain);
 }
 RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
@@ -718,7 +725,7 @@ RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
 }
 RT_DEV double t_hi(const TLane &L) { return L.med_ref ? L.sub_closest : L.closest; }
 RT_DEV void t_accept(TLane &L, double t, uint32_t face, uint32_t mat_word) {
-    if (L.med_ref) { L.sub_closest = t; L.sub_found = true; return; }
+    if (L.med_ref) { L.sub_closest = t; t_flag(L, kSubFound, true); return; }
     L.closest = t;
     L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx; L.win_mat = mat_word;
 }
@@ -751,14 +758,14 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK, WG> &st, double 
                 cnt.prim(RT_KIND_MEDIUM);
                 L.med_ref = L.top;
                 L.t_lo = -rtm::INF;
-                L.sub_closest = rtm::INF; L.sub_found = false;
+                L.sub_closest = rtm::INF; t_flag(L, kSubFound, false);
                 st.push(L, REF_MED1);
                 L.top = s.media_dev[RT_REF_INDEX(L.top)].boundary;
             } else if (L.top == REF_MED1) {
-                if (L.sub_found) {                                    // boundary.hit(r, rec1.t + 0.0001, inf)
+                if (L.flags & kSubFound) {                            // boundary.hit(r, rec1.t + 0.0001, inf)
                     L.med_t1 = L.sub_closest;
                     L.t_lo = L.med_t1 + 0.0001;
-                    L.sub_closest = rtm::INF; L.sub_found = false;
+                    L.sub_closest = rtm::INF; t_flag(L, kSubFound, false);
                     st.push(L, REF_MED2);
                     L.top = s.media_dev[RT_REF_INDEX(L.med_ref)].boundary;
                 } else {
@@ -849,9 +856,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     if (probe) t_start = wall_clock64();
 
     TLane L;
-    L.has_ray = false; L.plain = false; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
+    L.flags = 0; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
-    L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0; L.sub_found = false;
+    L.t_lo = t_min; L.sub_closest = rtm::INF; L.med_t1 = 0.0; L.med_ref = 0;
     L.ctx.c0 = L.ctx.c1 = L.ctx.c2 = L.ctx.c3 = 0; L.ctx.n = 0;
     L.win_chain = L.ctx; L.win_leaf = REF_EMPTY; L.win_face = 0; L.win_mat = 0;
     L.stash_ix = 0.0; L.stash_iz = 0.0; L.stash_level = 0xFFFFFFFFu;
@@ -874,7 +881,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         // The loop itself is a plain divergent loop over the node lanes — a lane that leaves the node state drops out
         // of it, and all that are left go together when their count falls below the threshold.
         {
-            bool isn = L.op == OP_NODE && L.plain;
+            bool isn = (L.op | (~L.flags & kPlain)) == 0u;             // a node step (OP_NODE is label 0) of a plain ray: one compare, one vote
             int nn = __popcll(wballot(isn));
             const int pending = __popcll(wballot(L.op != OP_IDLE));
             const int tail_threshold = tail_factor * pending / (tail_factor + 1) + 1;
@@ -1090,7 +1097,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 T_SETTLE();                                           // a medium leaf or a finished first query: same steps as inline
             } else if (L.top == REF_MED2) {
                 uint32_t mref = L.med_ref;
-                bool both = L.sub_found;
+                bool both = (L.flags & kSubFound) != 0;
                 double t2 = L.sub_closest;
                 L.med_ref = 0; L.t_lo = t_min;                        // back in the main query
                 if (both) {
@@ -1192,7 +1199,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         } else if (best == OP_SHADE) {
             // OP_SHADE here = "this lane's traversal is finished (or it has no ray yet)":
             // publish the winner, then pull the next ray from the block's list.
-            if (L.has_ray) {
+            if (L.flags & kHasRay) {
                 uint32_t slot = L.slot;
                 bool found = L.win_leaf != REF_EMPTY;
                 uint32_t kind = SK_MISS;
@@ -1203,7 +1210,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 }
                 pool.kind[L.entry] = (uint8_t)kind;                   // (by list position: see wf_shade)
                 if (L.rng.draws) { pv.store_rng(slot, L.rng.s); cnt.draws(L.rng.draws); }
-                L.has_ray = false;
+                t_flag(L, kHasRay, false);
             }
             const unsigned long long m = wballot(true);
             const int leader = __ffsll((long long)m) - 1;
@@ -1257,7 +1264,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.sp = 0;
                 L.top = s.root;
                 T_SETTLE();
-                L.has_ray = true;
+                t_flag(L, kHasRay, true);
             } else {
                 L.op = OP_IDLE;
             }
