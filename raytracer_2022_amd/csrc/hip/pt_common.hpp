@@ -119,22 +119,25 @@ struct Counters<true> {
 };
 
 // ---- movers: Translate / RotateY / Zoom (hittable/mod.rs:165-174,235-264,321-330) ----
-RT_DEV XRay xform_ray(const SceneDev &s, uint32_t ref, XRay r) {
-    const rt_xform &x = s.xforms[RT_REF_INDEX(ref)];
-    uint32_t kind = RT_REF_KIND(ref);
+// (the mover's three parameters by value: the caller decides where its record comes from)
+RT_DEV XRay xform_ray_p(uint32_t kind, double p0, double p1, double p2, XRay r) {
     if (kind == RT_KIND_TRANSLATE) {
-        r.o = r.o - ld3(x.p);
+        r.o = r.o - Vec3(p0, p1, p2);
     } else if (kind == RT_KIND_ROTATE_Y) {
-        double sin_theta = x.p[0], cos_theta = x.p[1];
+        double sin_theta = p0, cos_theta = p1;
         double ox = cos_theta * r.o.x - sin_theta * r.o.z;
         double oz = sin_theta * r.o.x + cos_theta * r.o.z;
         double dx = cos_theta * r.d.x - sin_theta * r.d.z;
         double dz = sin_theta * r.d.x + cos_theta * r.d.z;
         r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
     } else {
-        r.o = r.o / x.p[0];
+        r.o = r.o / p0;
     }
     return r;
+}
+RT_DEV XRay xform_ray(const SceneDev &s, uint32_t ref, XRay r) {
+    const rt_xform &x = s.xforms[RT_REF_INDEX(ref)];
+    return xform_ray_p(RT_REF_KIND(ref), x.p[0], x.p[1], x.p[2], r);
 }
 
 struct HitRec {                                // HitRecord, hittable/mod.rs:18-26

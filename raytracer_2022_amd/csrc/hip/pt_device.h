@@ -59,6 +59,7 @@ struct SceneDev {
     const MediumDev *media_dev;        // [n_media], traversal kernel's view of `media`
     uint32_t media_mode;               // 0: no medium has a plain-sphere boundary, 1: all have, 2: mixed (look at the record)
     uint32_t n_nodes;                  // records in `nodes`
+    uint32_t n_xforms, n_media;        // records in `xforms`, `media_dev`
 };
 
 // Counter block in HBM (same order as rt_stats' integer fields).
@@ -161,7 +162,10 @@ constexpr int kBlock = 256;
 // entries (64 KiB), and the first kNodeCache node records in the remaining LDS (56 bytes each: 97 440 B).
 constexpr int kCacheBlock = 1024;
 constexpr int kStackTiny = 16;
-constexpr int kNodeCache = 1740;
+#ifndef RT2022_NODE_CACHE
+#define RT2022_NODE_CACHE 1740
+#endif
+constexpr int kNodeCache = RT2022_NODE_CACHE;
 // Four traversal workgroups per CU = 4 waves per SIMD = a budget of 128 VGPRs: the kernel then needs 116 and spills
 // nothing. Five (96 VGPRs, 27 spilled, 84 B of scratch per lane) measured 3 % slower in the same run, three 8-9 %
 // slower (profiles/r2_ab_occupancy.log): the kernel is bound by instruction issue far more than by latency.

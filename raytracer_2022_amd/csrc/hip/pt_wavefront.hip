@@ -784,6 +784,21 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK, WG> &st, double 
 
 } // namespace
 
+// Phase clock of the traversal kernel (diagnostic build -DRT2022_TRACE_PROBE only): every wave adds the shader-clock
+// ticks it spent in each phase of the scheduler — [0] node fast path, [1] vote, [2..9] the voted arms by label (node,
+// sphere, rect, box, medium, misc, ctx, done), [10] the rest — to pool.dbg[96 + phase]; printed after the render.
+#ifdef RT2022_TRACE_PROBE
+#define TP_DECL __shared__ unsigned long long tp_lds[WG / 64][12]; unsigned long long tp_t = __builtin_readcyclecounter(); \
+    if (lane < 12) tp_lds[tid >> 6][lane] = 0
+#define TP_MARK(i) do { const unsigned long long tp_n = __builtin_readcyclecounter(); const unsigned long long tp_m = wballot(true); \
+    if ((int)lane == __ffsll((long long)tp_m) - 1) tp_lds[tid >> 6][(i)] += tp_n - tp_t; tp_t = tp_n; } while (0)
+#define TP_FLUSH() do { if (lane < 12 && pool.dbg) atomicAdd(&pool.dbg[96 + lane], tp_lds[tid >> 6][lane]); } while (0)
+#else
+#define TP_DECL do {} while (0)
+#define TP_MARK(i) do {} while (0)
+#define TP_FLUSH() do {} while (0)
+#endif
+
 // Resident traversal workgroups per CU a variant is built and launched for (= waves per SIMD = its VGPR budget):
 // the sphere-only kernel needs 82 VGPRs and runs five (C2: +4 % over four; six would spill), the full kernels four.
 constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
@@ -814,6 +829,11 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node.
     __shared__ f64x2 nc_box[CACHE > 0 ? 3 * CACHE : 1];
     __shared__ uint2 nc_ref[CACHE > 0 ? CACHE : 1];
+    // ... and, in the same variant, the first records of the two small tables the arms go to most: movers (32 B each)
+    // and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
+    constexpr uint32_t kLdsXforms = CACHE > 0 ? 8u : 0u, kLdsMedia = CACHE > 0 ? 2u : 0u;
+    __shared__ u32x4 xf_lds[kLdsXforms ? 2 * kLdsXforms : 1];
+    __shared__ f64x2 md_lds[kLdsMedia ? 4 * kLdsMedia : 1];
     const PoolView pv{pool};
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -828,9 +848,28 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
             nc_ref[i] = rr;
         }
+        if (tid < 2 * kLdsXforms && tid < 2 * s.n_xforms) xf_lds[tid] = reinterpret_cast<const u32x4 *>(s.xforms)[tid];
+        if (tid >= 64 && tid < 64 + 4 * kLdsMedia && tid < 64 + 4 * s.n_media) md_lds[tid - 64] = reinterpret_cast<const f64x2 *>(s.media_dev)[tid - 64];
         __syncthreads();
     }
+    // A mover's record {kind, child | p[0] | p[1], p[2]} from wherever it lives.
+    auto xform_words = [&](uint32_t idx, u32x4 &x0, f64x2 &x1) {
+        if (kLdsXforms && idx < kLdsXforms) { x0 = xf_lds[2 * idx]; x1 = reinterpret_cast<const f64x2 *>(xf_lds)[2 * idx + 1]; }
+        else { const u32x4 *xp = reinterpret_cast<const u32x4 *>(s.xforms + idx); x0 = xp[0]; x1 = reinterpret_cast<const f64x2 *>(xp)[1]; }
+    };
+    // ray_at_level of pt_common.hpp with the movers' records taken through xform_words.
+    auto ray_at = [&](const Chain &ch, uint32_t level, XRay r) {
+        for (uint32_t i = 0; i < level && i < RT_MAX_XFORM_DEPTH; i++) {
+            const uint32_t ref = ch.at(i);
+            u32x4 x0; f64x2 x1;
+            xform_words(RT_REF_INDEX(ref), x0, x1);
+            r = xform_ray_p(RT_REF_KIND(ref), rtm::u2d(((uint64_t)x0.w << 32) | x0.z), x1.x, x1.y, r);
+        }
+        return r;
+    };
     double *const wray = wray_lds + (kStash ? tid : 0u);
+    // (The node-table variant has no LDS left for the world rays and fetches them from the pool again. Keeping them in
+    // twelve more registers instead — 128 in all, nothing spilled — measured the same: +0.3 %, A/B.)
 
     // Work of a pass = the ray lists of all segments (written by the preceding shade pass), cut into chunks of
     // kChunk entries and numbered slice-major: chunk id -> (slice = id / segments, segment = id % segments), so
@@ -855,6 +894,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     bool dry_seen = false;
     if (probe) t_start = wall_clock64();
 
+    TP_DECL;
     TLane L;
     L.flags = 0; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
@@ -948,6 +988,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 nn = __popcll(wballot(isn));
             } while (isn && nn >= threshold);
         }
+        TP_MARK(0);
         // Vote: the label most lanes are waiting on (ties -> lowest id).
         int best = -1, best_n = 0;
 #pragma unroll
@@ -960,6 +1001,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
+        TP_MARK(1);
         if (STATS) {
             unsigned served = (unsigned)__popcll(wballot(L.op == (uint32_t)best));
             if (lane == 0) { census_rounds[best]++; census_lanes[best] += served; }
@@ -1060,9 +1102,15 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             u32x4 m3{0u, 0u, 0u, 0u};
             const bool is_leaf = RT_REF_KIND(L.top) == RT_KIND_MEDIUM;
             if (is_leaf) {
-                const f64x2 *mp = reinterpret_cast<const f64x2 *>(s.media_dev + RT_REF_INDEX(L.top));
-                m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
-                m3 = reinterpret_cast<const u32x4 *>(mp)[3];
+                const uint32_t midx = RT_REF_INDEX(L.top);
+                if (kLdsMedia && midx < kLdsMedia) {
+                    m0 = md_lds[4 * midx]; m1 = md_lds[4 * midx + 1]; m2 = md_lds[4 * midx + 2];
+                    m3 = reinterpret_cast<const u32x4 *>(md_lds)[4 * midx + 3];
+                } else {
+                    const f64x2 *mp = reinterpret_cast<const f64x2 *>(s.media_dev + midx);
+                    m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+                    m3 = reinterpret_cast<const u32x4 *>(mp)[3];
+                }
             }
             t_pin(m0); t_pin(m1); t_pin(m2); t_pin(m3);
             if (is_leaf && m3.x != 0u) {
@@ -1154,7 +1202,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     Ray wr = pv.load_ray(L.slot);
                     world = XRay{wr.orig, wr.dir};
                 }
-                L.cur = ray_at_level(s, L.ctx, L.ctx.n, world);
+                L.cur = ray_at(L.ctx, L.ctx.n, world);
                 if (left_kind == RT_KIND_ROTATE_Y) {
                     if (L.stash_level == L.ctx.n) { L.inv.x = L.stash_ix; L.inv.z = L.stash_iz; L.stash_level = 0xFFFFFFFFu; }
                     else { L.inv.x = 1.0 / L.cur.d.x; L.inv.z = 1.0 / L.cur.d.z; }
@@ -1170,9 +1218,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     for (uint32_t i = l.count; i > 0; i--) st.push(L, s.list_items[l.first + i - 1]);
                     T_NEXT();
                 } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
-                    const u32x4 *xp = reinterpret_cast<const u32x4 *>(s.xforms + idx);              // rt_xform, 32 B: kind, child, p[3]
-                    u32x4 x0 = xp[0];
-                    f64x2 x1 = reinterpret_cast<const f64x2 *>(xp)[1];
+                    u32x4 x0;                                         // rt_xform, 32 B: kind, child, p[3]
+                    f64x2 x1;
+                    xform_words(idx, x0, x1);
                     t_pin(x0); t_pin(x1);
                     const double p0 = rtm::u2d(((uint64_t)x0.w << 32) | x0.z), p1 = x1.x, p2 = x1.y;
                     if (kind == RT_KIND_TRANSLATE) {                  // Translate::hit, mod.rs:165-167
@@ -1269,7 +1317,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.op = OP_IDLE;
             }
         }
+        TP_MARK(2 + best);
     }
+    TP_FLUSH();
     if (probe && lane == 0) {
         unsigned long long t_end = wall_clock64();
         atomicMin(&pool.dbg[0], t_start);
@@ -1560,6 +1610,19 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
         (void)hipStreamSynchronize(stream);
         return e;
     }
+#ifdef RT2022_TRACE_PROBE
+    if (pool.dbg) {
+        unsigned long long h[12];
+        if (hipMemcpy(h, pool.dbg + 96, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *const names[12] = {"node_fast", "vote", "node", "sphere", "rect", "box", "medium", "misc", "ctx", "done", "rest", "-"};
+            double tot = 0; for (int i = 0; i < 11; i++) tot += (double)h[i];
+            fprintf(stderr, "trace probe (shader-clock ticks of all waves and passes; share):");
+            for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.3f", names[i], tot > 0 ? (double)h[i] / tot : 0.0);
+            fprintf(stderr, "  total %.3e ticks\n", tot);
+        }
+        (void)hipMemset(pool.dbg + 96, 0, 12 * sizeof(unsigned long long));
+    }
+#endif
 #ifdef RT2022_SHADE_PROBE
     if (pool.dbg) {
         unsigned long long h[10];

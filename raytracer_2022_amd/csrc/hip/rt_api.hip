@@ -454,9 +454,9 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         if (w.gs.n < 1) w.gs.n = 1;
         if (w.gs.n > kMaxGroups) w.gs.n = kMaxGroups;
         w.pool.dbg = timing ? w.pool_dbg : nullptr;
-#ifdef RT2022_SHADE_PROBE
-        w.pool.dbg = w.pool_dbg;                                  // (diagnostic build: the shade pass's section clock)
-        RT_HIP(hipMemsetAsync(w.pool_dbg + 64, 0, 10 * sizeof(unsigned long long), stream));
+#if defined(RT2022_SHADE_PROBE) || defined(RT2022_TRACE_PROBE)
+        w.pool.dbg = w.pool_dbg;                                  // (diagnostic builds: the section clocks of the shade / traversal kernels)
+        RT_HIP(hipMemsetAsync(w.pool_dbg + 64, 0, 48 * sizeof(unsigned long long), stream));
 #endif
         if (timing) for (double &t : sc->pass_timing) t = 0.0;
         a.tape = nullptr;
@@ -627,6 +627,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.root = desc->root;
             s.n_lights = desc->n_lights;
             s.n_nodes = desc->n_nodes;
+            s.n_xforms = desc->n_xforms;
+            s.n_media = desc->n_media;
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
             sc->boxes_plain = v.boxes_plain();
