@@ -23,7 +23,8 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  *         workgroup (1..8, default 8);
  *   20-23 s: every segment's ray list is ordered longest-first by (expected node steps) >> s, 0 = slot order;
  *   24-27 groups the pool is cut into, each alternating its passes on a stream of its own (1..8, default 1);
- *   28    (unused);
+ *   28    keep the BVH's node table out of LDS: the plain traversal kernels even where the node-table variant applies
+ *         (rt_debug_trace_variant says which one a scene takes);
  *   29    run the pass-timing probe (rt_debug_pass_timing);
  *   30    take the literal AABB step only (test hook).
  * vote_weights (megakernel only; the wavefront engine uses node 1, others 2): 4 bits per operation

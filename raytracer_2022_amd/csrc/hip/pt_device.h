@@ -208,7 +208,7 @@ hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp,
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 hipError_t launch_rng_probe(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n, hipStream_t stream);
 // Which traversal variant the wavefront engine launches for a scene without counters: {threads per workgroup, stack entries, nodes kept in LDS}.
-void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t out[3]);
+void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, uint32_t out[3]);
 // Occupancy-derived persistent grid size for the given variant.
 int render_grid_blocks(uint32_t stack_need, bool counters);
 

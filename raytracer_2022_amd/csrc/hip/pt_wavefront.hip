@@ -1400,10 +1400,11 @@ static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t 
     }
 }
 // Whether a scene takes the node-cache variant: its stacks fit the variant's, and its node table fits the cache whole.
-// (RT2022_NODE_CACHE=0 in the environment keeps the plain kernels: A/B runs.)
-static bool use_node_cache(const SceneDev &scene, uint32_t stack_need) {
+// (Bit 28 of the tuning word — rt_debug_set_tuning — or RT2022_NODE_CACHE=0 in the environment keeps the plain kernels:
+// A/B runs, and the test that the two give the same bits.)
+static bool use_node_cache(const SceneDev &scene, uint32_t stack_need, uint32_t tuning) {
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
-    return enabled && stack_need <= (uint32_t)kStackTiny && scene.n_nodes <= (uint32_t)kNodeCache;
+    return enabled && !(tuning & (1u << 28)) && stack_need <= (uint32_t)kStackTiny && scene.n_nodes <= (uint32_t)kNodeCache;
 }
 template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
@@ -1423,7 +1424,7 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (between) (void)hipEventRecord(between, w.stream);
-    if (!counters && !probe && use_node_cache(w.scene, stack_need)) {
+    if (!counters && !probe && use_node_cache(w.scene, stack_need, w.node_quorum)) {
         launch_trace_cached_feat(features, w, parity);
     } else if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
@@ -1590,8 +1591,8 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
     return hipSuccess;
 }
 
-void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t out[3]) {
-    if (use_node_cache(scene, stack_need)) { out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes; return; }
+void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, uint32_t out[3]) {
+    if (use_node_cache(scene, stack_need, tuning)) { out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes; return; }
     out[0] = (uint32_t)kBlock;
     out[1] = stack_need <= (uint32_t)kStackSmall ? (uint32_t)kStackSmall : stack_need <= (uint32_t)kStackMid ? (uint32_t)kStackMid : (uint32_t)kStackLarge;
     out[2] = 0;

@@ -1000,7 +1000,7 @@ int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, u
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_trace_variant: null scene");
         uint32_t v[3] = {0, 0, 0};
-        if (scene->engine == 1) trace_variant(scene->dev, scene->stack_need, v);
+        if (scene->engine == 1) trace_variant(scene->dev, scene->stack_need, scene->node_quorum, v);
         if (workgroup_threads) *workgroup_threads = v[0];
         if (stack_entries) *stack_entries = v[1];
         if (nodes_in_lds) *nodes_in_lds = v[2];

@@ -496,6 +496,25 @@ def test_one_call_over_a_device_mask(rt, O):
         rt.DeviceSceneSet(s.desc, 0)
 
 
+def test_node_table_variant_gives_the_same_bits(rt):
+    """The traversal variant that keeps the BVH's node table in LDS (1024-thread workgroups) against the plain kernels
+    (tuning bit 28): same pixels bit for bit, on every scene small enough to take it; big scenes do not take it."""
+    default = 18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24)
+    for name, expect_table in (("final_scene", True), ("random_scene", True), ("cornell_smoke", True), ("two_perlin_spheres", True)):
+        c, g, s, cam, p = golden_case(name, rt)
+        dev = rt.DeviceScene(s.desc)
+        v = dev.trace_variant()
+        assert (v["nodes_in_lds"] == s.desc.n_nodes and v["workgroup_threads"] == 1024) == expect_table, (name, v)
+        a = dev.render(cam, p, g["rows"])
+        dev.set_tuning(default | (1 << 28))
+        v2 = dev.trace_variant()
+        assert v2["nodes_in_lds"] == 0 and v2["workgroup_threads"] == 256, (name, v2)
+        b = dev.render(cam, p, g["rows"])
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(g["rgb_sum"])), name
+    big = rt.HostScene("wwscene", seed=5, param=1)
+    assert rt.DeviceScene(big.desc).trace_variant()["nodes_in_lds"] == 0
+
+
 def test_kernel_times_and_run_report(rt):
     """rt_stats says how the call ran (chunk, passes, pool) and, on request, the device time of the two kernels."""
     s = rt.HostScene("final_scene", seed=2022)
