@@ -807,14 +807,20 @@ constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
 // The node-cache variant (WG = kCacheBlock threads, one workgroup per CU, CACHE = kNodeCache records): the BVH's first
 // CACHE node records live in LDS — 48 bytes of box and 8 of child refs each — beside the traversal stacks of the
 // workgroup's 16 waves. A node step on a cached node is an LDS round trip instead of an L1 / L2 one; the 160 KiB of a
-// CU belong to ONE workgroup, so the table exists once per CU rather than once per four waves. The variant is launched
-// only for scenes whose whole node table fits (use_node_cache); same records, same arithmetic, same results.
+// CU belong to ONE workgroup, so the table exists once per CU rather than once per four waves. Two instances: the
+// whole node table of a small scene (PARTIAL = false: no HBM path for nodes at all), and the first kNodeCache records
+// of a larger one whose stacks still fit 16 entries (PARTIAL = true) — rt_scene_create numbers the nodes of the
+// device copy breadth-first from the root, so the first records are the top levels of the BVHs, the ones every ray
+// goes through. Same records, same arithmetic, same results. Measured (tools/scaling_scenes.py, 1200x800x160): 549
+// nodes +21 %, 12 213 nodes (1740 of them in LDS) +8.5 %. A third instance — 700 records beside stacks of 30 entries
+// for the deep BVHs of 131 K / 1 M / the 1.7 M-node mesh of C5 — measured -2 % / -4.5 % / +-0 and was dropped: the top
+// levels of a big BVH are L1-resident anyway, and what the table saves on a small one is the L2 latency of the levels below.
 constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg) {
     return wg == kBlock ? trace_blocks_per_cu(stack, stats, feat) : wg / 256;
 }
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
-template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0>
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false>
 __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, WG)) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
@@ -946,7 +952,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 const int below_sp = L.sp > 0 ? L.sp - 1 : 0;
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
-                if (CACHE > 0) {                                  // (this variant is launched only for scenes whose every node is in the table)
+                if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                     f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
                     uint2 cr = nc_ref[nidx];
                     below = st.col[below_sp * WG];
@@ -1014,7 +1020,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const uint32_t nidx = RT_REF_INDEX(L.top);
             f64x2 n0, n1, n2;
             u32x4 n3;
-            if (CACHE > 0) {                                  // (this variant is launched only for scenes whose every node is in the table)
+            if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const uint2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, cr.y, 0u, 0u};
@@ -1379,32 +1385,35 @@ static void launch_trace(const WfLaunch &w, uint32_t parity) {
                        w.node_quorum, parity, w.stats);
 }
 // The node-cache variant: one workgroup of kCacheBlock threads per CU (see wf_trace).
-template <unsigned FEAT>
+template <unsigned FEAT, int STACK, int CACHE, bool PARTIAL>
 static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
     const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
     if (grid > most) grid = most;
-    hipLaunchKernelGGL((wf_trace<kStackTiny, false, FEAT, false, kCacheBlock, kNodeCache>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
+    hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
                        w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats);
 }
+template <int STACK, int CACHE, bool PARTIAL>
 static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
     switch (feat & 7u) {
-        case 0: launch_trace_cached<0>(w, parity); break;
-        case 1: launch_trace_cached<1>(w, parity); break;
-        case 2: launch_trace_cached<2>(w, parity); break;
-        case 3: launch_trace_cached<3>(w, parity); break;
-        case 4: launch_trace_cached<4>(w, parity); break;
-        case 5: launch_trace_cached<5>(w, parity); break;
-        case 6: launch_trace_cached<6>(w, parity); break;
-        default: launch_trace_cached<7>(w, parity); break;
+        case 0: launch_trace_cached<0, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 1: launch_trace_cached<1, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 2: launch_trace_cached<2, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 3: launch_trace_cached<3, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 4: launch_trace_cached<4, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 5: launch_trace_cached<5, STACK, CACHE, PARTIAL>(w, parity); break;
+        case 6: launch_trace_cached<6, STACK, CACHE, PARTIAL>(w, parity); break;
+        default: launch_trace_cached<7, STACK, CACHE, PARTIAL>(w, parity); break;
     }
 }
 // Whether a scene takes the node-cache variant: its stacks fit the variant's, and its node table fits the cache whole.
 // (Bit 28 of the tuning word — rt_debug_set_tuning — or RT2022_NODE_CACHE=0 in the environment keeps the plain kernels:
 // A/B runs, and the test that the two give the same bits.)
-static bool use_node_cache(const SceneDev &scene, uint32_t stack_need, uint32_t tuning) {
+// 0: the plain kernels; 1: the whole table (stacks of 16); 2: its first kNodeCache records (stacks of 16).
+static int node_cache_mode(const SceneDev &scene, uint32_t stack_need, uint32_t tuning) {
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
-    return enabled && !(tuning & (1u << 28)) && stack_need <= (uint32_t)kStackTiny && scene.n_nodes <= (uint32_t)kNodeCache;
+    if (!enabled || (tuning & (1u << 28)) || stack_need > (uint32_t)kStackTiny) return 0;
+    return scene.n_nodes <= (uint32_t)kNodeCache ? 1 : 2;
 }
 template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
@@ -1424,8 +1433,11 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (between) (void)hipEventRecord(between, w.stream);
-    if (!counters && !probe && use_node_cache(w.scene, stack_need, w.node_quorum)) {
-        launch_trace_cached_feat(features, w, parity);
+    const int table = (counters || probe) ? 0 : node_cache_mode(w.scene, stack_need, w.node_quorum);
+    if (table == 1) {
+        launch_trace_cached_feat<kStackTiny, kNodeCache, false>(features, w, parity);
+    } else if (table == 2) {
+        launch_trace_cached_feat<kStackTiny, kNodeCache, true>(features, w, parity);
     } else if (stack_need <= (uint32_t)kStackSmall) {
         if (counters) launch_trace<kStackSmall, true, 7>(w, parity);
         else if (probe) launch_trace_feat<kStackSmall, true>(features, w, parity);   // (the probe exists per feature set for the small stack only)
@@ -1592,7 +1604,11 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
 }
 
 void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, uint32_t out[3]) {
-    if (use_node_cache(scene, stack_need, tuning)) { out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes; return; }
+    const int table = node_cache_mode(scene, stack_need, tuning);
+    if (table) {
+        out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < (uint32_t)kNodeCache ? scene.n_nodes : (uint32_t)kNodeCache;
+        return;
+    }
     out[0] = (uint32_t)kBlock;
     out[1] = stack_need <= (uint32_t)kStackSmall ? (uint32_t)kStackSmall : stack_need <= (uint32_t)kStackMid ? (uint32_t)kStackMid : (uint32_t)kStackLarge;
     out[2] = 0;

@@ -223,6 +223,35 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+// New index of every BVH node in the device copy: breadth-first from the root, through movers, lists and medium
+// boundaries. The traversal kernels keep the FIRST records of the node table in LDS (pt_wavefront.hip); numbered this
+// way those are the top levels of the BVHs — the nodes every ray goes through. (The flattener emits children before
+// parents; the order of the records means nothing to the results.)
+std::vector<uint32_t> breadth_first_nodes(const rt_scene_desc &d) {
+    std::vector<uint32_t> new_of(d.n_nodes, 0xFFFFFFFFu), queue;
+    std::vector<char> seen_x(d.n_xforms, 0), seen_l(d.n_lists, 0), seen_m(d.n_media, 0);
+    uint32_t next = 0;
+    queue.push_back(d.root);
+    for (size_t h = 0; h < queue.size(); h++) {
+        const uint32_t ref = queue[h], kind = RT_REF_KIND(ref), idx = RT_REF_INDEX(ref);
+        if (kind == RT_KIND_NODE) {
+            if (new_of[idx] != 0xFFFFFFFFu) continue;
+            new_of[idx] = next++;
+            queue.push_back(d.nodes[idx].left);
+            if (d.nodes[idx].right != d.nodes[idx].left) queue.push_back(d.nodes[idx].right);
+        } else if (kind >= RT_KIND_TRANSLATE && kind <= RT_KIND_ZOOM) {
+            if (!seen_x[idx]) { seen_x[idx] = 1; queue.push_back(d.xforms[idx].child); }
+        } else if (kind == RT_KIND_LIST) {
+            if (!seen_l[idx]) { seen_l[idx] = 1; for (uint32_t i = 0; i < d.lists[idx].count; i++) queue.push_back(d.list_items[d.lists[idx].first + i]); }
+        } else if (kind == RT_KIND_MEDIUM) {
+            if (!seen_m[idx]) { seen_m[idx] = 1; queue.push_back(d.media[idx].boundary); }
+        }
+    }
+    for (uint32_t i = 0; i < d.n_nodes; i++)
+        if (new_of[i] == 0xFFFFFFFFu) new_of[i] = next++;            // (unreachable nodes keep a place behind the others)
+    return new_of;
+}
+
 template <class T>
 T *upload(const T *src, uint64_t n, std::vector<void *> &owned) {
     // Never hand the kernels a null pool: an empty pool gets one zeroed element.
@@ -557,7 +586,20 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             RT_HIP(hipDeviceGetAttribute(&sc->n_cus, hipDeviceAttributeMultiprocessorCount, sc->device));
             RT_REQUIRE(sc->n_cus > 0, RT_ERR_DEVICE, "rt_scene_create: device reports no compute units");
             SceneDev &s = sc->dev;
-            s.nodes = upload(desc->nodes, desc->n_nodes, sc->owned);
+            // Node refs of the device copy follow the breadth-first numbering (breadth_first_nodes).
+            const std::vector<uint32_t> new_of = breadth_first_nodes(*desc);
+            auto node_ref = [&](uint32_t ref) {
+                return RT_REF_KIND(ref) == RT_KIND_NODE ? (ref & ~RT_REF_INDEX_MASK) | new_of[RT_REF_INDEX(ref)] : ref;
+            };
+            {
+                std::vector<rt_bvh_node> nodes(desc->n_nodes);
+                for (uint32_t i = 0; i < desc->n_nodes; i++) {
+                    rt_bvh_node q = desc->nodes[i];
+                    q.left = node_ref(q.left); q.right = node_ref(q.right);
+                    nodes[new_of[i]] = q;
+                }
+                s.nodes = upload(nodes.data(), nodes.size(), sc->owned);
+            }
             // Primitive pools go up with the slot kind of their material packed above the material index (pt_device.h).
             RT_REQUIRE(desc->n_materials <= kMatIndexMask, RT_ERR_UNSUPPORTED, "more than 2^24 materials");
             auto packed = [&](auto *src, uint64_t n) {
@@ -577,7 +619,11 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.boxes = packed(desc->boxes, desc->n_boxes);
             s.triangles = packed(desc->triangles, desc->n_triangles);
             s.rings = packed(desc->rings, desc->n_rings);
-            s.media = packed(desc->media, desc->n_media);
+            {
+                std::vector<rt_medium> media(desc->media, desc->media + desc->n_media);
+                for (rt_medium &m : media) m.boundary = node_ref(m.boundary);
+                s.media = packed(media.data(), media.size());
+            }
             {
                 std::vector<MediumDev> md(desc->n_media);
                 uint32_t n_sph = 0;
@@ -586,7 +632,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                     MediumDev &q = md[i];
                     std::memset(&q, 0, sizeof q);
                     q.neg_inv_density = m.neg_inv_density;
-                    q.boundary = m.boundary;
+                    q.boundary = node_ref(m.boundary);
                     q.mat = m.mat | ((uint32_t)SK_ISOTROPIC << kMatKindShift);
                     if (RT_REF_KIND(m.boundary) == RT_KIND_SPHERE && !(m.boundary & RT_REF_FLIP)) {
                         const rt_sphere &sp = desc->spheres[RT_REF_INDEX(m.boundary)];
@@ -598,9 +644,15 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 s.media_dev = upload(md.data(), md.size(), sc->owned);
                 s.media_mode = n_sph == 0 ? 0u : n_sph == desc->n_media ? 1u : 2u;
             }
-            s.xforms = upload(desc->xforms, desc->n_xforms, sc->owned);
+            {
+                std::vector<rt_xform> xforms(desc->xforms, desc->xforms + desc->n_xforms);
+                for (rt_xform &x : xforms) x.child = node_ref(x.child);
+                s.xforms = upload(xforms.data(), xforms.size(), sc->owned);
+                std::vector<uint32_t> items(desc->list_items, desc->list_items + desc->n_list_items);
+                for (uint32_t &r : items) r = node_ref(r);
+                s.list_items = upload(items.data(), items.size(), sc->owned);
+            }
             s.lists = upload(desc->lists, desc->n_lists, sc->owned);
-            s.list_items = upload(desc->list_items, desc->n_list_items, sc->owned);
             s.lights = upload(desc->lights, desc->n_lights, sc->owned);
             s.materials = upload(desc->materials, desc->n_materials, sc->owned);
             s.textures = upload(desc->textures, desc->n_textures, sc->owned);
@@ -624,7 +676,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.images = upload(desc->images, desc->n_images, sc->owned);
             s.image_data = upload(desc->image_data, desc->image_data_bytes, sc->owned);
             s.perlins = upload(desc->perlins, desc->n_perlins, sc->owned);
-            s.root = desc->root;
+            s.root = node_ref(desc->root);
             s.n_lights = desc->n_lights;
             s.n_nodes = desc->n_nodes;
             s.n_xforms = desc->n_xforms;

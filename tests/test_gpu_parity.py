@@ -498,7 +498,7 @@ def test_one_call_over_a_device_mask(rt, O):
 
 def test_node_table_variant_gives_the_same_bits(rt):
     """The traversal variant that keeps the BVH's node table in LDS (1024-thread workgroups) against the plain kernels
-    (tuning bit 28): same pixels bit for bit, on every scene small enough to take it; big scenes do not take it."""
+    (tuning bit 28): same pixels bit for bit, whether the whole table fits or only its first records."""
     default = 18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24)
     for name, expect_table in (("final_scene", True), ("random_scene", True), ("cornell_smoke", True), ("two_perlin_spheres", True)):
         c, g, s, cam, p = golden_case(name, rt)
@@ -511,8 +511,21 @@ def test_node_table_variant_gives_the_same_bits(rt):
         assert v2["nodes_in_lds"] == 0 and v2["workgroup_threads"] == 256, (name, v2)
         b = dev.render(cam, p, g["rows"])
         assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(g["rgb_sum"])), name
-    big = rt.HostScene("wwscene", seed=5, param=1)
-    assert rt.DeviceScene(big.desc).trace_variant()["nodes_in_lds"] == 0
+    # A scene whose node table does not fit keeps the top of its BVHs there (the device copy numbers the nodes breadth-first).
+    big = rt.HostScene("random_scene", seed=5, param=40)             # (81 x 81 grid: ~13 K nodes, stacks of 16 suffice)
+    dev = rt.DeviceScene(big.desc)
+    v = dev.trace_variant()
+    assert v["workgroup_threads"] == 1024 and 0 < v["nodes_in_lds"] < big.desc.n_nodes and v["stack_entries"] >= dev.info()["stack_need"], v
+    cam, bg = big.default_view(16 / 9)
+    p = rt.make_params(64, 36, 2, 50, bg, seed=5)
+    rows = np.arange(36, dtype=np.uint32)
+    a = dev.render(cam, p, rows)
+    dev.set_tuning(default | (1 << 28))
+    assert dev.trace_variant()["nodes_in_lds"] == 0
+    assert np.array_equal(bits(a), bits(dev.render(cam, p, rows)))
+    # ... and a BVH too deep for stacks of 16 entries takes the plain kernels
+    deep = rt.HostScene("wwscene", seed=5, param=1)
+    assert rt.DeviceScene(deep.desc).trace_variant()["nodes_in_lds"] == 0
 
 
 def test_kernel_times_and_run_report(rt):
