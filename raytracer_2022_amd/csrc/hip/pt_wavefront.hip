@@ -729,6 +729,36 @@ RT_DEV void t_accept(TLane &L, double t, uint32_t face, uint32_t mat_word) {
     L.closest = t;
     L.win_leaf = L.top; L.win_face = face; L.win_chain = L.ctx; L.win_mat = mat_word;
 }
+// The two boundary queries of ConstantMedium::hit on ONE sphere (constantmedium.rs:50-51):
+//     sphere_t(center, radius, r, a, -inf, +inf, t1)  and then  sphere_t(center, radius, r, a, t1 + 0.0001, +inf, t2)
+// with what they share — oc, half_b, c, the discriminant, its square root and the near root — computed once. Every
+// expression and comparison is sphere_t's own (pt_common.hpp, sphere.rs:39-58), so the values are the same bit for bit;
+// `first` says whether the first query found a hit (the second is only made, and counted, then).
+RT_DEV bool sphere_t_twice(Vec3 center, double radius, const XRay &r, double a, double &t1, double &t2, bool &first) {
+    first = false;
+    Vec3 oc = r.o - center;
+    double half_b = rtm::dot(oc, r.d);
+    double c = oc.length_sqr() - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrtd = rtm::sqrt_(discriminant);
+    const double near_root = (-half_b - sqrtd) / a;
+    double root = near_root;
+    if (root < -rtm::INF || rtm::INF < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < -rtm::INF || rtm::INF < root) return false;
+    }
+    t1 = root;
+    first = true;
+    const double t_min2 = t1 + 0.0001;
+    root = near_root;
+    if (root < t_min2 || rtm::INF < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min2 || rtm::INF < root) return false;
+    }
+    t2 = root;
+    return true;
+}
 // Boxes::hit over six sides given by value (boxes.rs:24-66,80-82 + mod.rs:90-100): box_t of pt_common.hpp, fed from
 // registers.
 RT_DEV bool t_box(double p0x, double p0y, double p0z, double p1x, double p1y, double p1z, const XRay &r, double t_min, double t_max,
@@ -1128,12 +1158,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 const uint32_t mat_word = (uint32_t)(rtm::d2u(m2.y) >> 32);
                 cnt.prim(RT_KIND_MEDIUM);
                 cnt.prim(RT_KIND_SPHERE);
-                double t1, t2 = 0.0;
-                bool both = sphere_t(center, q.radius, L.cur, L.a_len, -rtm::INF, rtm::INF, t1);
-                if (both) {
-                    cnt.prim(RT_KIND_SPHERE);
-                    both = sphere_t(center, q.radius, L.cur, L.a_len, t1 + 0.0001, rtm::INF, t2);
-                }
+                double t1 = 0.0, t2 = 0.0;
+                bool first;
+                const bool both = sphere_t_twice(center, q.radius, L.cur, L.a_len, t1, t2, first);
+                if (first) cnt.prim(RT_KIND_SPHERE);
                 if (both) {
                     t1 = rtm::fmax_(t1, t_min);
                     t2 = rtm::fmin_(t2, L.closest);
