@@ -43,7 +43,12 @@ constexpr int S = kSlotsPerBlock;
 #ifndef RT2022_LIST_OCTANTS
 #define RT2022_LIST_OCTANTS 1
 #endif
-constexpr uint32_t kListBins = 16 * 8;     // list order: 16 classes of expected length x 8 direction octants
+#ifndef RT2022_LIST_ORIGIN
+#define RT2022_LIST_ORIGIN 1           // 0: no third key; 1: four classes (camera / sphere / box, rect / medium); 2: eight (the leaf kind itself)
+#endif
+// list order: 16 classes of expected length x classes of where the ray starts x 8 direction octants
+constexpr uint32_t kOriginClasses = RT2022_LIST_ORIGIN == 2 ? 8u : RT2022_LIST_ORIGIN ? 4u : 1u;
+constexpr uint32_t kListBins = 16 * kOriginClasses * 8;
 constexpr uint32_t kChunk = RT2022_CHUNK;           // list entries a wave claims at a time
 
 // Records are fetched whole and at once — a few 16-byte loads issued back to back and waited for together — never
@@ -519,7 +524,11 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
             store_state(pool, slot, stt, false);
             uint32_t cls = step_shift ? (expect >> step_shift) : 0u;
             new_kind[slot - base] = (uint8_t)(SK_TRACE | ((cls > 15u ? 15u : cls) << 4));
-            new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
+            // (third key, RT2022_LIST_ORIGIN: what the ray starts from — a sphere, a box / rect, a medium)
+            const uint32_t lk = RT_REF_KIND(w.leaf);
+            const uint32_t org = RT2022_LIST_ORIGIN == 2 ? (lk & 7u)
+                               : RT2022_LIST_ORIGIN ? ((lk == RT_KIND_SPHERE || lk == RT_KIND_MOVING_SPHERE) ? 1u : (lk == RT_KIND_BOX || lk == RT_KIND_RECT) ? 2u : lk == RT_KIND_MEDIUM ? 3u : 0u) : 0u;
+            new_oct[slot - base] = (uint8_t)((RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u) | (org << 3));
         }
     }
 
@@ -624,7 +633,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     }
     SP_MARK(6);                                                      // 6: second sweep (new paths)
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
-    if (tid < kListBins) bins[tid] = 0;
+    for (uint32_t k = tid; k < kListBins; k += kBlock) bins[k] = 0;
     __syncthreads();
     // The segment's ray list, longest expected traversal first (counting sort, 16 classes): the stragglers of
     // the trace pass then start early instead of keeping a few lanes busy after the list has run dry.
@@ -635,13 +644,32 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         uint32_t key = kListBins;                                      // carries no ray
         // (second key: rays that point into the same octant meet the boxes in a similar pattern, and the lanes of a
         // wave draw neighbouring list entries)
-        if ((e & 0xFu) == SK_TRACE) { key = (15u - (e >> 4)) * 8u + new_oct[i * kBlock + tid]; atomicAdd(&bins[key], 1u); }
+        if ((e & 0xFu) == SK_TRACE) { key = (15u - (e >> 4)) * (8u * kOriginClasses) + new_oct[i * kBlock + tid]; atomicAdd(&bins[key], 1u); }
         my_key[i] = key;
     }
     __syncthreads();
+    // Exclusive prefix sums of the bins, in place: every thread takes kPer consecutive bins; scan over the wave by
+    // shuffles, over the four waves through LDS.
+    constexpr uint32_t kPer = kListBins > (uint32_t)kBlock ? kListBins / (uint32_t)kBlock : 1u;
+    static_assert(kPer * (uint32_t)kBlock >= kListBins, "bins per thread");
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    {
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) { const uint32_t k = tid * kPer + j; v[j] = k < kListBins ? bins[k] : 0u; sum += v[j]; }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d); if ((int)lane >= d) inc += t; }
+        if (lane == 63) wave_tot[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t excl = inc - sum;
+        for (uint32_t wv = 0; wv < (tid >> 6); wv++) excl += wave_tot[wv];
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) { const uint32_t k = tid * kPer + j; if (k < kListBins) bins[k] = excl; excl += v[j]; }
+    }
     if (tid == 0) {
         uint32_t acc = 0;
-        for (int k = 0; k < (int)kListBins; k++) { uint32_t n = bins[k]; bins[k] = acc; acc += n; }
+        for (int wv = 0; wv < kBlock / 64; wv++) acc += wave_tot[wv];
         pool.list_n[blockIdx.x] = acc;
         // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
         // turns, so each pass can clear the one the next pass will add to.
@@ -930,6 +958,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     bool dry_seen = false;
     if (probe) t_start = wall_clock64();
 
+#ifndef RT2022_REFILL_TOUCH
+#define RT2022_REFILL_TOUCH 1
+#endif
+    uint32_t touch_word = 0;
     TP_DECL;
     TLane L;
     L.flags = 0; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
@@ -1298,6 +1330,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const int leader = __ffsll((long long)m) - 1;
             uint32_t need = (uint32_t)__popcll(m);
             uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t rank0 = rank;
             uint32_t entry_idx = 0xFFFFFFFFu;                         // index into pool.list of the entry this lane takes
             const u32x4 cs_now = *cs;
             uint32_t ch_base = cs_now.x, ch_n = cs_now.y, ch_taken = cs_now.z;
@@ -1324,12 +1357,29 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             }
             if ((int)lane == leader) *cs = (u32x4){ch_base, ch_n, ch_taken, drained ? 1u : 0u};
             if (probe && !dry_seen && drained) { dry_seen = true; t_dry = wall_clock64(); }
+#if RT2022_REFILL_TOUCH
+            // Touch-ahead: the entries this wave's NEXT refill round will hand out follow the ones handed out now; each
+            // refilling lane asks for one word of the ray record of the entry `its rank` places further on, beside its own
+            // fetches (same two dependent round trips, issued in parallel) — the next round's records then come from L2 or
+            // the Infinity Cache instead of HBM. The word is never used: the empty asm at the head of the next refill
+            // gives the load a consumer.
+            asm volatile("" :: "v"(touch_word));
+            const uint32_t touch_entry = ch_base + ch_taken + rank0;
+            const bool touch = touch_entry < ch_base + ch_n;
+            uint32_t touch_local = 0;
+            if (touch) touch_local = pool.list[touch_entry];
+#endif
             if (entry_idx != 0xFFFFFFFFu) {
                 const uint32_t sbase = entry_idx & ~((uint32_t)S - 1u);
                 L.entry = entry_idx;
                 L.slot = sbase + pool.list[entry_idx];
                 uint64_t rs;
                 Ray wr = pv.load_ray(L.slot, rs);
+#if RT2022_REFILL_TOUCH
+                asm volatile("" ::: "memory");
+                if (touch) touch_word = *reinterpret_cast<const uint32_t *>(pool.ray + (uint64_t)((touch_entry & ~((uint32_t)S - 1u)) + touch_local) * kRecDoubles);
+                asm volatile("" ::: "memory");
+#endif
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);

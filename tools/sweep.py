@@ -23,7 +23,7 @@ dev = rt.DeviceScene(s.desc)
 pc = rt.make_params(W, H, 20, 50, bg, seed=2022, spp_chunk=1)
 out, st = dev.render(cam, pc, rows, want_stats=True)
 rays = st.rays * (spp / 20.0)
-def Q(q=18, segs=6, shift=2):
+def Q(q=18, segs=8, shift=2):
     return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (1 << 24)
 cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (1, 3)]
 p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
