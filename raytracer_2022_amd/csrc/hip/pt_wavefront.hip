@@ -1065,7 +1065,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (!(FEAT & kFeatMovers) && o == (int)OP_CTX) continue;
             if (!(FEAT & kFeatVolumes) && (o == (int)OP_BOX || o == (int)OP_MEDIUM)) continue;
             int n = __popcll(wballot(L.op == (uint32_t)o));
-            int score = o == (int)OP_NODE ? n : 2 * n;                // a node step outside the fast path yields to everything else (1.5x and 3x measured the same)
+#ifndef RT2022_DONE_WEIGHT
+#define RT2022_DONE_WEIGHT 1           // (publish + refill yields to the other arms: fewer, fuller refill rounds — +3 % on the headline, A/B)
+#endif
+            int score = o == (int)OP_NODE ? n : o == (int)OP_SHADE ? RT2022_DONE_WEIGHT * n : 2 * n;   // a node step outside the fast path yields to everything else (1.5x and 3x measured the same)
             if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
@@ -1154,6 +1157,12 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (rect_t((uint32_t)am, q0.x, q0.y, q1.x, q1.y, q2.x, L.cur, L.t_lo, t_hi(L), t)) t_accept(L, t, 0, (uint32_t)(am >> 32));
             T_NEXT();
         } else if ((FEAT & kFeatVolumes) && best == OP_BOX) {
+            // (like the spheres: the leaves of a box BVH come in pairs, a lane whose next entry is a box again takes it in the same turn)
+#ifndef RT2022_BOX_REPS
+#define RT2022_BOX_REPS 2
+#endif
+#pragma unroll 1
+            for (int rep = 0; rep < RT2022_BOX_REPS && L.op == OP_BOX; rep++) {
             cnt.prim(RT_KIND_BOX);
             const uint32_t bidx = RT_REF_INDEX(L.top);
             const f64x2_a8 *bp = reinterpret_cast<const f64x2_a8 *>(s.boxes + bidx);                // rt_box, 56 B: p0, p1, mat
@@ -1164,6 +1173,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             uint32_t face = 0;
             if (t_box(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face, mat_word);
             T_NEXT();
+            }
         } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83
             // (the medium's record — boundary sphere inline — in one fetch: MediumDev, pt_device.h)
             f64x2 m0{0.0, 0.0}, m1{0.0, 0.0}, m2{0.0, 0.0};
@@ -1233,6 +1243,11 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 T_NEXT();
             }
         } else if ((FEAT & kFeatMisc) && best == OP_MISC) {                                 // Triangle, Ring
+#ifndef RT2022_MISC_REPS
+#define RT2022_MISC_REPS 2
+#endif
+#pragma unroll 1
+            for (int rep = 0; rep < RT2022_MISC_REPS && L.op == OP_MISC; rep++) {
             uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
             cnt.prim(kind);
             double t;
@@ -1253,6 +1268,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             }
             if (h) t_accept(L, t, 0, mat_word);
             T_NEXT();
+            }
         } else if ((FEAT & kFeatMovers) && best == OP_CTX) {                                  // movers in / out, HittableList expansion
             // 1/d of the ray changes only where d does: RotateY (x and z). Translate and Zoom leave the direction alone
             // (hittable/mod.rs:165-167,321-323), so entering or leaving them keeps inv and a_len — the same values the
