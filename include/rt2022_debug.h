@@ -27,9 +27,10 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  *         (rt_debug_trace_variant says which one a scene takes);
  *   29    run the pass-timing probe (rt_debug_pass_timing);
  *   30    take the literal AABB step only (test hook).
- * vote_weights (megakernel only; the wavefront engine uses node 1, others 2): 4 bits per operation
- * label (node, sphere, rect, box, medium, misc, ctx, done); the vote picks the label with the largest
- * lanes * weight. All of this affects speed only, never results. */
+ * vote_weights: 4 bits per operation label from the lowest nibble up (node, sphere, rect, box, medium, misc,
+ * ctx, done = publish + refill); the vote picks the label with the largest lanes * weight; 0 = the engine's
+ * default (wavefront 0x24444442: node steps outside the fast path and the refill yield to the arms; megakernel
+ * 0x22222221). All of this affects speed only, never results. */
 int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_weights);
 /* Engine behind rt_render*: 1 (default) = wavefront passes (pt_wavefront.hip), 0 = the single
  * megakernel (pt_kernel.hip). max_pool_blocks: segments of 4096 path slots in the pool (0 = the default of the tuning word).

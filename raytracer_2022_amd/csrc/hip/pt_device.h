@@ -158,6 +158,10 @@ constexpr int kStackSmall = 22;   // 22 KiB of LDS per workgroup; the lean kerne
 constexpr int kStackMid = 30;     // million-triangle meshes need ~26 entries; built for four workgroups per CU
 constexpr int kStackLarge = 64;
 constexpr int kBlock = 256;
+// Vote weights of the traversal schedulers, four bits per operation label from the lowest nibble up: node, sphere, rect,
+// box, medium, misc, ctx, done (publish + refill). The wave runs the label with the largest lanes x weight.
+constexpr uint32_t kWfVoteWeights = 0x24444442u;      // wavefront engine: node and refill yield to the arms
+constexpr uint32_t kMegaVoteWeights = 0x22222221u;    // megakernel
 // Node-cache variant of the traversal kernel (pt_wavefront.hip): one workgroup of 1024 threads per CU, stacks of 16
 // entries (64 KiB), and the first kNodeCache node records in the remaining LDS (56 bytes each: 97 440 B).
 constexpr int kCacheBlock = 1024;

@@ -880,7 +880,8 @@ constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg)
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
 template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false>
 __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, WG)) wf_trace(const SceneDev s, const WfPool pool,
-                                                   const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats) {
+                                                   const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats,
+                                                   const uint32_t vote_weights) {
     // (Scene and pool by value: pointer members of kernel arguments are known to be global
     // memory, so node / ray fetches compile to global_load instead of flat_load, and none of
     // them is re-read from a descriptor in memory inside the traversal loop.)
@@ -1065,10 +1066,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (!(FEAT & kFeatMovers) && o == (int)OP_CTX) continue;
             if (!(FEAT & kFeatVolumes) && (o == (int)OP_BOX || o == (int)OP_MEDIUM)) continue;
             int n = __popcll(wballot(L.op == (uint32_t)o));
-#ifndef RT2022_DONE_WEIGHT
-#define RT2022_DONE_WEIGHT 1           // (publish + refill yields to the other arms: fewer, fuller refill rounds — +3 % on the headline, A/B)
-#endif
-            int score = o == (int)OP_NODE ? n : o == (int)OP_SHADE ? RT2022_DONE_WEIGHT * n : 2 * n;   // a node step outside the fast path yields to everything else (1.5x and 3x measured the same)
+            // Weights, four bits per label (rt_debug_set_tuning; default kWfVoteWeights): a node step outside the fast path and
+            // the refill yield to everything else — node 2, refill 2, the rest 4 (refill at 4: -3 % on the headline, A/B).
+            int score = n * (int)((vote_weights >> (4 * o)) & 0xFu);
             if (score > best_n) { best_n = score; best = o; }
         }
         if (best < 0) break;                                          // every lane idle
@@ -1476,7 +1476,7 @@ static void launch_trace(const WfLaunch &w, uint32_t parity) {
     const uint32_t most = w.blocks * ((uint32_t)S / kChunk / 4u);
     if (grid > most) grid = most;
     hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(grid), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
-                       w.node_quorum, parity, w.stats);
+                       w.node_quorum, parity, w.stats, w.vote_weights);
 }
 // The node-cache variant: one workgroup of kCacheBlock threads per CU (see wf_trace).
 template <unsigned FEAT, int STACK, int CACHE, bool PARTIAL>
@@ -1485,7 +1485,7 @@ static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
     if (grid > most) grid = most;
     hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
-                       w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats);
+                       w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
 }
 template <int STACK, int CACHE, bool PARTIAL>
 static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {

@@ -303,7 +303,7 @@ struct rt_scene {
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
     uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(8 * 4096 / kSlotsPerBlock > 0 ? 8 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 8 segments per resident trace workgroup (4 per CU: 8192 segments = 33.5 M slots); list classes of 4 node steps
-    uint32_t vote_weights = 0x22222221u;       // "done" (publish + refill) yields to traversal work
+    uint32_t vote_weights = 0;                 // 0: the engine's own default (kWfVoteWeights / kMegaVoteWeights, pt_device.h)
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
     int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
@@ -445,7 +445,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     }
     // bit 31: boxes are plain (see wf_trace's fast path); bit 30 of the tuning word forces the literal step
     a.node_quorum = (sc->node_quorum & 0x7FFFFFFFu) | ((sc->boxes_plain && !(sc->node_quorum & (1u << 30))) ? (1u << 31) : 0u);
-    a.vote_weights = sc->vote_weights;
+    a.vote_weights = sc->vote_weights ? sc->vote_weights : (sc->engine == 1 ? kWfVoteWeights : kMegaVoteWeights);
     a.work_counter = w.work_counter;
     a.stats = counters ? w.stats : nullptr;
     if (sc->engine == 1) {
@@ -1003,7 +1003,8 @@ int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_wei
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_tuning: null scene");
         RT_REQUIRE((node_quorum & 0xFFu) >= 1 && (node_quorum & 0xFFu) <= 64 && true, RT_ERR_INVALID, "rt_debug_set_tuning: node_quorum must be 1..64 (+ extra sphere repeats << 8, + tail factor << 12, + segments per trace workgroup << 16, + long-first class shift << 20, + groups << 24, + 1 << 29: pass-timing probe, + 1 << 30: literal node step only)");
-        for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
+        if (vote_weights != 0)                  // (0 = the engine's default)
+            for (int o = 0; o < 8; o++) RT_REQUIRE(((vote_weights >> (4 * o)) & 0xFu) != 0, RT_ERR_INVALID, "rt_debug_set_tuning: a vote weight is 0");
         scene->node_quorum = node_quorum;
         scene->vote_weights = vote_weights;
         return RT_OK;

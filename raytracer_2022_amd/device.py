@@ -24,7 +24,7 @@ class DeviceScene:
         F.check(F.lib().rt_debug_trace_variant(self._h, C.byref(wg), C.byref(st), C.byref(nc)))
         return {"workgroup_threads": wg.value, "stack_entries": st.value, "nodes_in_lds": nc.value}
 
-    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24), vote_weights=0x22222221):
+    def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24), vote_weights=0):
         F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))
 
     def set_engine(self, engine, max_pool_blocks=0):

@@ -26,10 +26,23 @@ rays = st.rays * (spp / 20.0)
 def Q(q=18, segs=8, shift=2):
     return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (1 << 24)
 cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (1, 3)]
+# vote weights (nibbles from the lowest: node, sphere, rect, box, medium, misc, ctx, done); 0 = the engine's default
+def WT(node=2, sphere=4, rect=4, box=4, medium=4, misc=4, ctx=4, done=2):
+    return node | (sphere << 4) | (rect << 8) | (box << 12) | (medium << 16) | (misc << 20) | (ctx << 24) | (done << 28)
+wcfgs = [('w_default', 0), ('w_done1', WT(done=1)), ('w_done3', WT(done=3)), ('w_done4', WT(done=4)), ('w_med6', WT(medium=6)), ('w_med3', WT(medium=3)), ('w_sph3', WT(sphere=3)),
+         ('w_sph6', WT(sphere=6)), ('w_box6', WT(box=6)), ('w_box3', WT(box=3)), ('w_ctx3', WT(ctx=3)), ('w_ctx6', WT(ctx=6)), ('w_node3', WT(node=3)), ('w_node1', WT(node=1)),
+         ('w_exp', WT(sphere=3, box=5, medium=6, ctx=3, done=2))]
 p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
 dev.set_tuning(Q()); run(dev, cam, p, rows, W)
+which = sys.argv[3] if len(sys.argv) > 3 else 'knobs'
 for rep in range(2):
-    for tag, q in cfgs:
-        dev.set_tuning(q)
-        ms = run(dev, cam, p, rows, W)
-        print('%-8s %8.1f ms  %7.1f Mrays/s' % (tag, ms, rays / ms / 1e3), flush=True)
+    if which in ('knobs', 'all'):
+        for tag, q in cfgs:
+            dev.set_tuning(q)
+            ms = run(dev, cam, p, rows, W)
+            print('%-8s %8.1f ms  %7.1f Mrays/s' % (tag, ms, rays / ms / 1e3), flush=True)
+    if which in ('weights', 'all'):
+        for tag, wt in wcfgs:
+            dev.set_tuning(Q(), wt)
+            ms = run(dev, cam, p, rows, W)
+            print('%-10s %8.1f ms  %7.1f Mrays/s' % (tag, ms, rays / ms / 1e3), flush=True)

@@ -33,7 +33,7 @@ t = dev.pass_timing()
 print('pass timing (probe run %.1f ms): %s' % (ms, t))
 print('  mean wave lifetime / pass span = %.3f   dry tail / lifetime = %.3f' % (t['wave_life_ms'] / t['span_ms'], t['wave_dry_ms'] / t['wave_life_ms']), flush=True)
 # (segments in the pool, tuning word): pool sizes around the default, then quorum and list-class granularity
-cfgs = [('wavefront', b, 1, Q(), 0x22222221, None) for b in (0, 3840, 5120, 10240)] + [('wavefront', 0, 1, Q(q=q, shift=sh), 0x22222221, None) for q, sh in ((12, 2), (24, 2), (18, 1), (18, 3))]
+cfgs = [('wavefront', b, 1, Q(), 0, None) for b in (0, 3840, 5120, 10240)] + [('wavefront', 0, 1, Q(q=q, shift=sh), 0, None) for q, sh in ((12, 2), (24, 2), (18, 1), (18, 3))]
 for eng, blocks, chunk, q, wts, pc in cfgs:
     dev.set_engine(eng, blocks); dev.set_tuning(q, wts)
     p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=chunk)
