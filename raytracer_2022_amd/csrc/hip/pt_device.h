@@ -79,6 +79,7 @@ struct RenderArgs {
     uint32_t chunk, n_chunks;          // samples per work item, items per pixel
     double background[3];
     double t_min;
+    double split[3];                   // centre of the root's bounding box (ordering of the ray lists only)
     uint64_t seed;
     uint64_t n_pixels;                 // n_rows * width
     uint64_t n_items;                  // n_pixels * n_chunks

@@ -302,6 +302,7 @@ struct rt_scene {
     unsigned features = 7;
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
+    double split[3] = {0.0, 0.0, 0.0};         // centre of the root's box (list ordering)
     uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(8 * 4096 / kSlotsPerBlock > 0 ? 8 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 8 segments per resident trace workgroup (4 per CU: 8192 segments = 33.5 M slots); list classes of 4 node steps
     uint32_t vote_weights = 0;                 // 0: the engine's own default (kWfVoteWeights / kMegaVoteWeights, pt_device.h)
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
@@ -424,6 +425,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     a.n_chunks = p->spp == 0 ? 1 : (p->spp + chunk - 1) / chunk;
     std::memcpy(a.background, p->background, sizeof a.background);
     a.t_min = p->t_min;
+    std::memcpy(a.split, sc->split, sizeof a.split);
     a.seed = p->seed;
     a.n_pixels = (uint64_t)p->n_rows * p->width;
     a.n_items = a.n_pixels * a.n_chunks;
@@ -684,6 +686,10 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
             sc->boxes_plain = v.boxes_plain();
+            if (RT_REF_KIND(desc->root) == RT_KIND_NODE) {
+                const rt_bvh_node &rn = desc->nodes[RT_REF_INDEX(desc->root)];
+                for (int ax = 0; ax < 3; ax++) { const double c = 0.5 * (rn.bmin[ax] + rn.bmax[ax]); sc->split[ax] = std::isfinite(c) ? c : 0.0; }
+            }
             sc->features = ((desc->n_triangles || desc->n_rings) ? kFeatMisc : 0u) |
                            ((desc->n_xforms || desc->n_lists) ? kFeatMovers : 0u) |
                            ((desc->n_boxes || desc->n_media) ? kFeatVolumes : 0u);
