@@ -588,6 +588,17 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     // (The barrier also makes the first sweep's pixel sums visible to whichever thread finishes the item here.)
     __syncthreads();
     const uint32_t n_want = n_fresh;
+    // One sample per item: every slot on the queue takes a new item, so the segment claims them with ONE atomic instead
+    // of one per wave and sweep turn (RT2022_ITEM_BATCH; which slot gets which item changes nothing, §5 of DESIGN.md).
+#ifndef RT2022_ITEM_BATCH
+#define RT2022_ITEM_BATCH 1
+#endif
+    __shared__ unsigned long long seg_items;
+    const bool batch = RT2022_ITEM_BATCH && single;
+    if (batch) {
+        if (tid == 0) seg_items = n_want ? atomicAdd(a.work_counter, (unsigned long long)n_want) : 0ull;
+        __syncthreads();
+    }
     for (uint32_t j0 = 0; j0 < n_want; j0 += kBlock) {
         const uint32_t j = j0 + tid;
         const bool on = j < n_want;
@@ -617,10 +628,12 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 if (m) {
                     int leader = __ffsll((long long)m) - 1;
                     unsigned long long wbase = 0;
-                    if ((int)lane == leader) wbase = atomicAdd(a.work_counter, (unsigned long long)__popcll(m));
-                    wbase = __shfl(wbase, leader);
+                    if (!batch) {
+                        if ((int)lane == leader) wbase = atomicAdd(a.work_counter, (unsigned long long)__popcll(m));
+                        wbase = __shfl(wbase, leader);
+                    }
                     if (need) {
-                        unsigned long long item = wbase + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                        unsigned long long item = batch ? seg_items + j : wbase + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
                         if (item < a.n_items) {
                             uint64_t pix_slot, yi;
                             uint32_t chunk_id, px;
