@@ -352,46 +352,11 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     const bool small_job = a.n_items <= 0xFFFFFFFFull;
     const uint32_t step_shift = (a.node_quorum >> 20) & 0xFu;         // list class = expected steps >> shift (0 = slot order)
 
-#ifndef RT2022_SHADE_PIPE
-#define RT2022_SHADE_PIPE 1
-#endif
-    // (RT2022_SHADE_PIPE: the hit record of a slot is fetched one loop turn ahead — 32 bytes, eight registers across the
-    // turn — so that the primitive and material fetches that depend on it go out together with the slot's state and ray
-    // instead of a round trip later.)
-    u32x4 ha_next{0u, 0u, 0u, 0u}, hb_next{0u, 0u, 0u, 0u};
-    u32x4 sa_next{0u, 0u, 0u, 0u}, sb_next{0u, 0u, 0u, 0u};          // (RT2022_SHADE_PIPE == 2: the state and the ray too)
-    f64x2 ra_next{0.0, 0.0}, rb_next{0.0, 0.0}, rc_next{0.0, 0.0}, rd_next{0.0, 0.0};
-    auto fetch_ahead = [&](uint32_t jj) {
-        if (jj < total) {
-            const uint32_t e = sorted[jj];
-            const uint64_t sl = (uint64_t)(base + (e & 0xFFFFu));
-            if (RT2022_SHADE_PIPE == 2) {
-                const u32x4 *sq = reinterpret_cast<const u32x4 *>(pool.state + sl * kRecWords);
-                sa_next = sq[0]; sb_next = sq[1];
-            }
-            if ((e >> 16) > SK_MISS) {
-                const u32x4 *hq = reinterpret_cast<const u32x4 *>(pool.hit + sl * kRecWords);
-                ha_next = hq[0]; hb_next = hq[1];
-                if (RT2022_SHADE_PIPE == 2) {
-                    const f64x2 *rq = reinterpret_cast<const f64x2 *>(pool.ray + sl * kRecDoubles);
-                    ra_next = rq[0]; rb_next = rq[1]; rc_next = rq[2]; rd_next = rq[3];
-                }
-            }
-        }
-    };
-    if (RT2022_SHADE_PIPE) fetch_ahead(tid);
     for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
         const uint32_t j = j0 + tid;
         const bool on = j < total;
         uint32_t slot = 0, kind = SK_IDLE;
         if (on) { uint32_t e = sorted[j]; slot = base + (e & 0xFFFFu); kind = e >> 16; }
-        u32x4 ha_now = ha_next, hb_now = hb_next, sa_now = sa_next, sb_now = sb_next;
-        f64x2 ra_now = ra_next, rb_now = rb_next, rc_now = rc_next, rd_now = rd_next;
-        if (RT2022_SHADE_PIPE) {
-            t_pin(ha_now); t_pin(hb_now);                            // (this turn's record has had a whole turn to arrive)
-            if (RT2022_SHADE_PIPE == 2) { t_pin(sa_now); t_pin(sb_now); t_pin(ra_now); t_pin(rb_now); t_pin(rc_now); t_pin(rd_now); }
-            fetch_ahead(j + kBlock);
-        }
         // Every slot that carried a ray has been through the trace pass by now. One that has not would lose its
         // path without a trace (it is neither shaded nor re-listed): report it instead — the render then fails.
         if (on && kind == SK_TRACE) atomicOr(pool.fault, 1u);
@@ -411,25 +376,14 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         PrimRegs prim{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
         f64x2 md0{0.0, 0.0}, md1{0.0, 0.0}, md2{0.0, 0.0}, md3{0.0, 0.0}, md4{0.0, 0.0};      // MaterialDev
         if (on) {
-            if (RT2022_SHADE_PIPE == 2) {
-                stt.item = ((uint64_t)sa_now.y << 32) | sa_now.x;
-                stt.smp = sa_now.z; stt.smp_end = sa_now.w; stt.depth = sb_now.x; stt.px = sb_now.y; stt.py = sb_now.z; stt.frame = sb_now.w;
-            } else {
-                stt = load_state(pool, slot);
-            }
+            stt = load_state(pool, slot);
             if (kind > SK_MISS) {                                 // (a miss ends its path and a fresh slot has none: neither needs the ray or the winner)
                 uint64_t rs;
-                if (RT2022_SHADE_PIPE == 2) {
-                    rs = rtm::d2u(rd_now.y);
-                    r = Ray(Vec3(ra_now.x, ra_now.y, rb_now.x), Vec3(rb_now.y, rc_now.x, rc_now.y), rd_now.x);
-                } else {
-                    r = pv.load_ray(slot, rs);
-                }
+                r = pv.load_ray(slot, rs);
                 rng = Rng(rs);
                 const u32x4 *hq = reinterpret_cast<const u32x4 *>(pool.hit + (uint64_t)slot * kRecWords);
-                u32x4 ha, hb;
-                if (RT2022_SHADE_PIPE) { ha = ha_now; hb = hb_now; }
-                else { ha = hq[0]; hb = hq[1]; t_pin(ha); t_pin(hb); }
+                u32x4 ha = hq[0], hb = hq[1];
+                t_pin(ha); t_pin(hb);
                 bool have_mat;
                 PoolView::decode_hit(ha, hb, w, steps, mat_word, have_mat);
                 if (!have_mat) mat_word = leaf_material_word(s, w.leaf);      // (four movers deep: the chain needed the word's place)
