@@ -398,6 +398,10 @@ def main():
         nodes_in_lds = tv["nodes_in_lds"] >= scene.desc.n_nodes and tv["nodes_in_lds"] > 0
         lds_bytes = BYTES_NODE_LDS * counts["node_visits"] if nodes_in_lds else 0
         cache_bytes = ab["traversal"] - (BYTES_NODE * counts["node_visits"] if nodes_in_lds else 0)
+        if tv.get("spheres_in_lds"):       # (small sphere-only scenes: both sphere pools are LDS tables too, 36 / 80 B per test)
+            k_s, k_m = F.KIND_NAMES.index("sphere"), F.KIND_NAMES.index("moving_sphere")
+            lds_bytes += 36 * counts["prim_tests"][k_s] + 80 * counts["prim_tests"][k_m]
+            cache_bytes -= BYTES_PRIM["sphere"] * counts["prim_tests"][k_s] + BYTES_PRIM["moving_sphere"] * counts["prim_tests"][k_m]
 
         roof = {
             "bound": "hbm", "kernel": "wf_trace (BVH traversal + Hittable::hit, pt_wavefront.hip): %.0f %% of the frame's device time" % (100.0 * tr_ms / k_ms if k_ms else 0),
@@ -486,7 +490,7 @@ def main():
             roof["lds"] = {"achieved": rnd(gbs(lds_bytes, tr_ms)), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s", "frac": frac(gbs(lds_bytes, tr_ms), LDS_PEAK_GBS),
                            "bytes_per_step": int(lds_bytes),
                            "what": "%d B per node visit from the workgroup's node table (3 x ds_read_b128 + ds_read_b64 at random records: bank conflicts "
-                                   "make the usable rate a third to a quarter of the conflict-free peak)" % BYTES_NODE_LDS}
+                                   "make the usable rate a third to a quarter of the conflict-free peak)%s" % (BYTES_NODE_LDS, "; the sphere pools too" if tv.get("spheres_in_lds") else "")}
             limiter.append(("lds", roof["lds"]["frac"]))
         if limiter:
             limiter.sort(key=lambda kv: -(kv[1] or 0))

@@ -54,9 +54,10 @@ int rt_debug_traffic_probe(int mode, uint64_t buffer_bytes, uint64_t n_access, u
 /* Traversal-stack entries the scene needs and the persistent grid size used for it. */
 int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
 /* The traversal kernel variant the scene's timed renders (no RT_FLAG_COUNTERS) take: threads per workgroup, stack
- * entries per lane, and how many of the scene's node records the workgroup keeps in LDS (0: the plain kernels, every
- * node fetched through L1 / L2). */
-int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds);
+ * entries per lane, how many of the scene's node records the workgroup keeps in LDS (0: the plain kernels, every
+ * node fetched through L1 / L2), and whether its Sphere / MovingSphere pools are there too (1: small sphere-only scenes). */
+int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds,
+                           uint32_t *spheres_in_lds);
 
 #ifdef __cplusplus
 }

@@ -208,7 +208,7 @@ def lib():
     L.rt_debug_math_device.argtypes = [C.c_int, P(dbl), P(dbl), P(dbl), u64]
     L.rt_debug_rng_device.argtypes = [u64, C.c_int, dbl, dbl, u64, P(u64), u64]
     L.rt_debug_scene_info.argtypes = [vp, P(u32), P(i32)]
-    L.rt_debug_trace_variant.argtypes = [vp, P(u32), P(u32), P(u32)]
+    L.rt_debug_trace_variant.argtypes = [vp, P(u32), P(u32), P(u32), P(u32)]
     L.rt_debug_set_tuning.argtypes = [vp, u32, u32]
     L.rt_debug_set_engine.argtypes = [vp, C.c_int, C.c_int]
     L.rt_debug_census.argtypes = [vp, P(u64), P(u64)]

@@ -60,6 +60,7 @@ struct SceneDev {
     uint32_t media_mode;               // 0: no medium has a plain-sphere boundary, 1: all have, 2: mixed (look at the record)
     uint32_t n_nodes;                  // records in `nodes`
     uint32_t n_xforms, n_media;        // records in `xforms`, `media_dev`
+    uint32_t n_spheres, n_moving_spheres;
 };
 
 // Counter block in HBM (same order as rt_stats' integer fields).
@@ -171,6 +172,9 @@ constexpr int kStackTiny = 16;
 #define RT2022_NODE_CACHE 1740
 #endif
 constexpr int kNodeCache = RT2022_NODE_CACHE;
+// The all-in-LDS instance for small sphere-only scenes: 600 node records (33 600 B), 256 Sphere records (36 B each) and
+// 512 MovingSphere records (80 B each) beside the 64 KiB of stacks.
+constexpr int kPrimNodes = 600, kPrimSpheres = 256, kPrimMoving = 512;
 // Four traversal workgroups per CU = 4 waves per SIMD = a budget of 128 VGPRs: the kernel then needs 116 and spills
 // nothing. Five (96 VGPRs, 27 spilled, 84 B of scratch per lane) measured 3 % slower in the same run, three 8-9 %
 // slower (profiles/r2_ab_occupancy.log): the kernel is bound by instruction issue far more than by latency.
@@ -213,7 +217,7 @@ hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp,
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 hipError_t launch_rng_probe(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n, hipStream_t stream);
 // Which traversal variant the wavefront engine launches for a scene without counters: {threads per workgroup, stack entries, nodes kept in LDS}.
-void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, uint32_t out[3]);
+void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features, uint32_t out[4]);
 // Occupancy-derived persistent grid size for the given variant.
 int render_grid_blocks(uint32_t stack_need, bool counters);
 

@@ -901,7 +901,7 @@ constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg)
 }
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
-template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false>
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false, bool PRIMS = false>
 __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, WG)) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats,
                                                    const uint32_t vote_weights) {
@@ -922,6 +922,11 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     constexpr uint32_t kLdsXforms = CACHE > 0 ? 8u : 0u, kLdsMedia = CACHE > 0 ? 2u : 0u;
     __shared__ u32x4 xf_lds[kLdsXforms ? 2 * kLdsXforms : 1];
     __shared__ f64x2 md_lds[kLdsMedia ? 4 * kLdsMedia : 1];
+    // PRIMS (sphere-only scenes small enough, C2): the sphere pools too — 32 B of centre and radius + 4 B of material
+    // word per Sphere, the 80-byte record per MovingSphere; launched only when both pools fit whole.
+    __shared__ f64x2 sp_lds[PRIMS ? 2 * kPrimSpheres : 1];
+    __shared__ uint32_t spm_lds[PRIMS ? kPrimSpheres : 1];
+    __shared__ f64x2 ms_lds[PRIMS ? 5 * kPrimMoving : 1];
     const PoolView pv{pool};
     const uint32_t tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -935,6 +940,15 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const uint2 rr = reinterpret_cast<const uint2 *>(np)[6];
             nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
             nc_ref[i] = rr;
+        }
+        if (PRIMS) {
+            for (uint32_t i = tid; i < s.n_spheres && i < (uint32_t)kPrimSpheres; i += (uint32_t)WG) {
+                const f64x2_a8 *qp = reinterpret_cast<const f64x2_a8 *>(s.spheres + i);
+                sp_lds[2 * i] = qp[0]; sp_lds[2 * i + 1] = qp[1];
+                spm_lds[i] = s.spheres[i].mat;
+            }
+            for (uint32_t i = tid; i < 5u * s.n_moving_spheres && i < 5u * (uint32_t)kPrimMoving; i += (uint32_t)WG)
+                ms_lds[i] = reinterpret_cast<const f64x2 *>(s.moving_spheres)[i];
         }
         if (tid < 2 * kLdsXforms && tid < 2 * s.n_xforms) xf_lds[tid] = reinterpret_cast<const u32x4 *>(s.xforms)[tid];
         if (tid >= 64 && tid < 64 + 4 * kLdsMedia && tid < 64 + 4 * s.n_media) md_lds[tid - 64] = reinterpret_cast<const f64x2 *>(s.media_dev)[tid - 64];
@@ -1154,13 +1168,17 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 double radius;
                 uint32_t mat_word;
                 if (kind == RT_KIND_SPHERE) {                         // rt_sphere, 40 B: center, radius, mat
-                    const f64x2_a8 *qp = reinterpret_cast<const f64x2_a8 *>(s.spheres + idx);
-                    f64x2 q0 = qp[0], q1 = qp[1];
-                    mat_word = s.spheres[idx].mat;
+                    f64x2 q0, q1;
+                    if (PRIMS) { q0 = sp_lds[2 * idx]; q1 = sp_lds[2 * idx + 1]; mat_word = spm_lds[idx]; }
+                    else {
+                        const f64x2_a8 *qp = reinterpret_cast<const f64x2_a8 *>(s.spheres + idx);
+                        q0 = qp[0]; q1 = qp[1];
+                        mat_word = s.spheres[idx].mat;
+                    }
                     t_pin(q0); t_pin(q1); t_pin(mat_word);
                     center = Vec3(q0.x, q0.y, q1.x); radius = q1.y;
                 } else {                                              // rt_moving_sphere, 80 B: center0, center1, time0, time1, radius, mat
-                    const f64x2 *qp = reinterpret_cast<const f64x2 *>(s.moving_spheres + idx);
+                    const f64x2 *qp = PRIMS ? ms_lds + 5 * idx : reinterpret_cast<const f64x2 *>(s.moving_spheres + idx);
                     f64x2 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3], q4 = qp[4];
                     t_pin(q0); t_pin(q1); t_pin(q2); t_pin(q3); t_pin(q4);
                     const Vec3 c0(q0.x, q0.y, q1.x), c1(q1.y, q2.x, q2.y);
@@ -1515,6 +1533,14 @@ static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
                        w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
 }
+// The all-in-LDS instance for sphere-only scenes (FEAT = 0): node table of kPrimNodes records and both sphere pools.
+static void launch_trace_prims(const WfLaunch &w, uint32_t parity) {
+    uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
+    const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
+    if (grid > most) grid = most;
+    hipLaunchKernelGGL((wf_trace<kStackTiny, false, 0, false, kCacheBlock, kPrimNodes, false, true>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
+                       w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
+}
 template <int STACK, int CACHE, bool PARTIAL>
 static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
     switch (feat & 7u) {
@@ -1531,10 +1557,14 @@ static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t 
 // Whether a scene takes the node-cache variant: its stacks fit the variant's, and its node table fits the cache whole.
 // (Bit 28 of the tuning word — rt_debug_set_tuning — or RT2022_NODE_CACHE=0 in the environment keeps the plain kernels:
 // A/B runs, and the test that the two give the same bits.)
-// 0: the plain kernels; 1: the whole table (stacks of 16); 2: its first kNodeCache records (stacks of 16).
-static int node_cache_mode(const SceneDev &scene, uint32_t stack_need, uint32_t tuning) {
+// 0: the plain kernels; 1: the whole table (stacks of 16); 2: its first kNodeCache records (stacks of 16); 3: a
+// sphere-only scene whose node table and sphere pools all fit (RT2022_PRIM_TABLES=0 in the environment: mode 1 instead).
+static int node_cache_mode(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features) {
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
+    static const bool prims = [] { const char *e = getenv("RT2022_PRIM_TABLES"); return !(e && e[0] == '0'); }();
     if (!enabled || (tuning & (1u << 28)) || stack_need > (uint32_t)kStackTiny) return 0;
+    if (prims && features == 0 && scene.n_nodes <= (uint32_t)kPrimNodes && scene.n_spheres <= (uint32_t)kPrimSpheres &&
+        scene.n_moving_spheres <= (uint32_t)kPrimMoving) return 3;
     return scene.n_nodes <= (uint32_t)kNodeCache ? 1 : 2;
 }
 template <int STACK, bool PROBE = false>
@@ -1555,8 +1585,10 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
     if (counters) launch_shade<true>(w, parity);
     else launch_shade<false>(w, parity);
     if (between) (void)hipEventRecord(between, w.stream);
-    const int table = (counters || probe) ? 0 : node_cache_mode(w.scene, stack_need, w.node_quorum);
-    if (table == 1) {
+    const int table = (counters || probe) ? 0 : node_cache_mode(w.scene, stack_need, w.node_quorum, features);
+    if (table == 3) {
+        launch_trace_prims(w, parity);
+    } else if (table == 1) {
         launch_trace_cached_feat<kStackTiny, kNodeCache, false>(features, w, parity);
     } else if (table == 2) {
         launch_trace_cached_feat<kStackTiny, kNodeCache, true>(features, w, parity);
@@ -1725,10 +1757,12 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
     return hipSuccess;
 }
 
-void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, uint32_t out[3]) {
-    const int table = node_cache_mode(scene, stack_need, tuning);
+void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features, uint32_t out[4]) {
+    out[3] = 0;
+    const int table = node_cache_mode(scene, stack_need, tuning, features);
     if (table) {
         out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < (uint32_t)kNodeCache ? scene.n_nodes : (uint32_t)kNodeCache;
+        out[3] = table == 3 ? 1u : 0u;
         return;
     }
     out[0] = (uint32_t)kBlock;

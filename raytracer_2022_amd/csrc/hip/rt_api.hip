@@ -683,6 +683,8 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.n_nodes = desc->n_nodes;
             s.n_xforms = desc->n_xforms;
             s.n_media = desc->n_media;
+            s.n_spheres = desc->n_spheres;
+            s.n_moving_spheres = desc->n_moving_spheres;
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
             sc->boxes_plain = v.boxes_plain();
@@ -1055,14 +1057,16 @@ int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *gr
     });
 }
 
-int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds) {
+int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds,
+                           uint32_t *spheres_in_lds) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_trace_variant: null scene");
-        uint32_t v[3] = {0, 0, 0};
-        if (scene->engine == 1) trace_variant(scene->dev, scene->stack_need, scene->node_quorum, v);
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (scene->engine == 1) trace_variant(scene->dev, scene->stack_need, scene->node_quorum, scene->features, v);
         if (workgroup_threads) *workgroup_threads = v[0];
         if (stack_entries) *stack_entries = v[1];
         if (nodes_in_lds) *nodes_in_lds = v[2];
+        if (spheres_in_lds) *spheres_in_lds = v[3];
         return RT_OK;
     });
 }

@@ -20,9 +20,9 @@ class DeviceScene:
 
     def trace_variant(self):
         """The traversal kernel variant timed renders of this scene take (rt_debug_trace_variant)."""
-        wg, st, nc = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        F.check(F.lib().rt_debug_trace_variant(self._h, C.byref(wg), C.byref(st), C.byref(nc)))
-        return {"workgroup_threads": wg.value, "stack_entries": st.value, "nodes_in_lds": nc.value}
+        wg, st, nc, sp = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        F.check(F.lib().rt_debug_trace_variant(self._h, C.byref(wg), C.byref(st), C.byref(nc), C.byref(sp)))
+        return {"workgroup_threads": wg.value, "stack_entries": st.value, "nodes_in_lds": nc.value, "spheres_in_lds": bool(sp.value)}
 
     def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24), vote_weights=0):
         F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))
