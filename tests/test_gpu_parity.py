@@ -505,6 +505,7 @@ def test_node_table_variant_gives_the_same_bits(rt):
         dev = rt.DeviceScene(s.desc)
         v = dev.trace_variant()
         assert (v["nodes_in_lds"] == s.desc.n_nodes and v["workgroup_threads"] == 1024) == expect_table, (name, v)
+        assert v["spheres_in_lds"] == (name in ("random_scene", "two_perlin_spheres")), (name, v)    # (the sphere-only scenes of the four)
         a = dev.render(cam, p, g["rows"])
         dev.set_tuning(default | (1 << 28))
         v2 = dev.trace_variant()
