@@ -917,9 +917,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node.
     __shared__ f64x2 nc_box[CACHE > 0 ? 3 * CACHE : 1];
     __shared__ uint2 nc_ref[CACHE > 0 ? CACHE : 1];
-    // ... and, in the same variant, the first records of the two small tables the arms go to most: movers (32 B each)
-    // and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
-    constexpr uint32_t kLdsXforms = CACHE > 0 ? 8u : 0u, kLdsMedia = CACHE > 0 ? 2u : 0u;
+    // ... and, in every variant (384 bytes), the first records of the two small tables the arms go to most: movers (32 B
+    // each) and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
+#ifndef RT2022_SMALL_TABLES_EVERYWHERE
+#define RT2022_SMALL_TABLES_EVERYWHERE 1
+#endif
+    constexpr bool kSmall = CACHE > 0 || RT2022_SMALL_TABLES_EVERYWHERE;
+    constexpr uint32_t kLdsXforms = kSmall && (FEAT & kFeatMovers) ? 8u : 0u, kLdsMedia = kSmall && (FEAT & kFeatVolumes) ? 2u : 0u;
     __shared__ u32x4 xf_lds[kLdsXforms ? 2 * kLdsXforms : 1];
     __shared__ f64x2 md_lds[kLdsMedia ? 4 * kLdsMedia : 1];
     // PRIMS (sphere-only scenes small enough, C2): the sphere pools too — 32 B of centre and radius + 4 B of material
@@ -950,6 +954,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             for (uint32_t i = tid; i < 5u * s.n_moving_spheres && i < 5u * (uint32_t)kPrimMoving; i += (uint32_t)WG)
                 ms_lds[i] = reinterpret_cast<const f64x2 *>(s.moving_spheres)[i];
         }
+    }
+    if (kLdsXforms || kLdsMedia || CACHE > 0) {
         if (tid < 2 * kLdsXforms && tid < 2 * s.n_xforms) xf_lds[tid] = reinterpret_cast<const u32x4 *>(s.xforms)[tid];
         if (tid >= 64 && tid < 64 + 4 * kLdsMedia && tid < 64 + 4 * s.n_media) md_lds[tid - 64] = reinterpret_cast<const f64x2 *>(s.media_dev)[tid - 64];
         __syncthreads();
