@@ -665,7 +665,12 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         // (new_oct: octant | origin class << 3 | quadrant << 6 — contiguous fields when every key is in use)
         if ((e & 0xFu) == SK_TRACE) {
             const uint32_t o8 = new_oct[i * kBlock + tid];
-            key = ((15u - (e >> 4)) * kSpatialClasses + (o8 >> 6)) * (8u * kOriginClasses) + (o8 & 63u);
+#ifndef RT2022_LIST_MAJOR
+#define RT2022_LIST_MAJOR 1            // 0: expected length first, then origin and octant; 1: origin and octant first, length within; 2: octant, origin, length
+#endif
+            if (RT2022_LIST_MAJOR == 1) key = ((o8 >> 6) * (8u * kOriginClasses) + (o8 & 63u)) * 16u + (15u - (e >> 4));
+            else if (RT2022_LIST_MAJOR == 2) key = (((o8 >> 6) * 8u + (o8 & 7u)) * kOriginClasses + ((o8 >> 3) & 7u)) * 16u + (15u - (e >> 4));
+            else key = ((15u - (e >> 4)) * kSpatialClasses + (o8 >> 6)) * (8u * kOriginClasses) + (o8 & 63u);
             atomicAdd(&bins[key], 1u);
         }
         my_key[i] = key;
