@@ -49,7 +49,7 @@ constexpr int S = kSlotsPerBlock;
 // list order: 16 classes of expected length x classes of where the ray starts x 8 direction octants
 constexpr uint32_t kOriginClasses = RT2022_LIST_ORIGIN == 2 ? 8u : RT2022_LIST_ORIGIN ? 4u : 1u;
 #ifndef RT2022_LIST_SPATIAL
-#define RT2022_LIST_SPATIAL 0          // 1: a fourth key, the quadrant (x, z about the centre of the root's box) the ray starts in
+#define RT2022_LIST_SPATIAL 0          // a fourth key — 1: the quadrant (x, z about the centre of the root's box) the ray starts in; 2: the dominant axis of its direction
 #endif
 constexpr uint32_t kSpatialClasses = RT2022_LIST_SPATIAL ? 4u : 1u;
 constexpr uint32_t kListBins = 16 * kOriginClasses * 8 * kSpatialClasses;
@@ -532,7 +532,9 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
             const uint32_t lk = RT_REF_KIND(w.leaf);
             const uint32_t org = RT2022_LIST_ORIGIN == 2 ? (lk & 7u)
                                : RT2022_LIST_ORIGIN ? ((lk == RT_KIND_SPHERE || lk == RT_KIND_MOVING_SPHERE) ? 1u : (lk == RT_KIND_BOX || lk == RT_KIND_RECT) ? 2u : lk == RT_KIND_MEDIUM ? 3u : 0u) : 0u;
-            const uint32_t quad = RT2022_LIST_SPATIAL ? ((r.orig.x < a.split[0] ? 1u : 0u) | (r.orig.z < a.split[2] ? 2u : 0u)) : 0u;
+            const double adx = rtm::fabs_(r.dir.x), ady = rtm::fabs_(r.dir.y), adz = rtm::fabs_(r.dir.z);
+            const uint32_t quad = RT2022_LIST_SPATIAL == 2 ? ((adx >= ady && adx >= adz) ? 0u : (ady >= adz ? 1u : 2u))
+                                : RT2022_LIST_SPATIAL ? ((r.orig.x < a.split[0] ? 1u : 0u) | (r.orig.z < a.split[2] ? 2u : 0u)) : 0u;
             new_oct[slot - base] = (uint8_t)((RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u) | (org << 3) | (quad << 6));
         }
     }

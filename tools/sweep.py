@@ -25,7 +25,7 @@ out, st = dev.render(cam, pc, rows, want_stats=True)
 rays = st.rays * (spp / 20.0)
 def Q(q=18, segs=8, shift=2):
     return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (1 << 24)
-cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (1, 3)]
+cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (0, 1, 2, 3, 4, 5)]
 # vote weights (nibbles from the lowest: node, sphere, rect, box, medium, misc, ctx, done); 0 = the engine's default
 def WT(node=2, sphere=4, rect=4, box=4, medium=4, misc=4, ctx=4, done=2):
     return node | (sphere << 4) | (rect << 8) | (box << 12) | (medium << 16) | (misc << 20) | (ctx << 24) | (done << 28)
