@@ -246,6 +246,65 @@ def cpu_baseline(scene, cam, params, height, seed, target_s):
     return out
 
 
+def spawn_ranks(n):
+    """Start `n` copies of this command as rank processes (children, never an exec), one per GPU, with the rendezvous
+    variables torch.distributed reads; relay rank 0's stdout (the JSON line) and return the worst exit code.
+    Nothing in this process has imported torch, loaded librt2022.so or made a HIP call when the children start
+    (RT2022_BENCH_SPAWN_REPORT=<file> writes what is loaded at that moment — tests/test_bench_spawn.py)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    report = os.environ.get("RT2022_BENCH_SPAWN_REPORT")
+    if report:
+        with open("/proc/self/maps") as fh:
+            libs = sorted({line.split()[-1] for line in fh if ".so" in line})
+        with open(report, "w") as fh:
+            json.dump({"modules": sorted(sys.modules), "shared_objects": libs}, fh)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("RT2022_BENCH_SPAWN_REPORT", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    worst = 0
+    failed_at = None
+    out0 = b""
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                if r == 0:
+                    try:
+                        out0, _ = procs[0].communicate(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        continue
+                elif procs[r].poll() is None:
+                    continue
+                live.discard(r)
+                rc = procs[r].returncode
+                if rc != 0:
+                    worst = rc if worst == 0 or abs(rc) > abs(worst) else worst
+                    if failed_at is None:
+                        failed_at = time.time()
+            # a rank that failed leaves the others waiting at a collective: give them a moment, then end them (these PIDs only)
+            if failed_at is not None and live and time.time() - failed_at > 20.0:
+                for r in live:
+                    procs[r].kill()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if worst < 0:                           # killed by a signal
+        worst = 128 - worst
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,6 +330,11 @@ def main():
     if args.inner_frame:
         inner_frame(args)
         return
+
+    # `python3 bench.py --gpus N` by itself (no torch.distributed.run around it): this process becomes the launcher —
+    # the reference's main() spawning and joining its workers, main.rs:109-183 — BEFORE anything here has touched the GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
