@@ -159,7 +159,7 @@ ABI_SYMBOLS = [
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
     "rtb_last_error", "rtb_abi_sizes",
-    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe",
+    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe", "rt_debug_valu_probe",
 ]
 
 _lib = None
@@ -214,6 +214,7 @@ def lib():
     L.rt_debug_census.argtypes = [vp, P(u64), P(u64)]
     L.rt_debug_pass_timing.argtypes = [vp, P(dbl)]
     L.rt_debug_traffic_probe.argtypes = [C.c_int, u64, u64, u64]
+    L.rt_debug_valu_probe.argtypes = [C.c_int, u32]
     _lib = L
     return L
 

@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     __shared__ uint32_t bins[kListBins];
     __shared__ uint8_t new_oct[S];       // direction octant of the slot's next ray (second sort key of the list)
     __shared__ uint16_t fresh_q[S];      // slots that want a new path (| 0x8000: the slot holds an item whose state counts)
+    static_assert(kSlotsPerBlock <= 32768 && kSlotsPerBlock % kBlock == 0, "a segment's slot index shares a u16 with one flag bit (fresh_q), and the sorts deal S / kBlock slots to every thread");
+    static_assert(kSlotsPerBlock <= 65536, "`sorted` packs slot | kind << 16");
     __shared__ uint32_t n_fresh;
     const RenderArgs &a = *ap;
     const PoolView pv{pool};
@@ -559,7 +561,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         const uint32_t j = j0 + tid;
         const bool on = j < n_want;
         const uint32_t e = on ? (uint32_t)fresh_q[j] : 0u;
-        const uint32_t slot = base + (e & 0x0FFFu);
+        const uint32_t slot = base + (e & 0x7FFFu);                   // (bit 15 is the flag; a segment holds at most 32768 slots)
         bool alive = false;
         Ray r;
         Rng rng;

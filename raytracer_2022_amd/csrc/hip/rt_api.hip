@@ -291,6 +291,7 @@ struct Workspace {
     uint32_t used_chunk = 0, used_passes = 0;
     uint64_t used_slots = 0;
     uint32_t *rows_max = nullptr;     // device word: largest row id of the call being checked
+    uint32_t *h_rows_max = nullptr;   // ... and the pinned word it is copied to
 };
 
 } // namespace
@@ -398,22 +399,30 @@ __global__ void __launch_bounds__(256) row_ids_max_kernel(const uint32_t *rows, 
     for (int d = 32; d > 0; d >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)m, d); m = o > m ? o : m; }
     if ((threadIdx.x & 63u) == 0 && m) atomicMax(out, m);
 }
-void check_device_rows(Workspace &w, const rt_params *p, hipStream_t stream) {
+// Two halves, so that the check costs a render no synchronisation of its own: the reduction and the copy of
+// its answer to a pinned word are enqueued with the call's other preparations, and the answer is looked at behind the
+// synchronisation the call makes anyway before its first pass. (A row id out of range cannot fault a kernel — it only
+// mis-keys a frame — so nothing is lost by finding out a moment later.)
+void begin_check_device_rows(Workspace &w, const rt_params *p, hipStream_t stream) {
     if (p->n_rows == 0) return;
-    if (!w.rows_max) RT_HIP(hipMalloc((void **)&w.rows_max, sizeof(uint32_t)));
+    if (!w.rows_max) {
+        RT_HIP(hipMalloc((void **)&w.rows_max, sizeof(uint32_t)));
+        RT_HIP(hipHostMalloc((void **)&w.h_rows_max, sizeof(uint32_t)));
+    }
     RT_HIP(hipMemsetAsync(w.rows_max, 0, sizeof(uint32_t), stream));
     uint32_t blocks = (p->n_rows + 255u) / 256u;
     hipLaunchKernelGGL(row_ids_max_kernel, dim3(blocks > 64 ? 64 : blocks), dim3(256), 0, stream, p->row_ids, p->n_rows, w.rows_max);
     RT_HIP(hipGetLastError());
-    uint32_t h = 0;
-    RT_HIP(hipMemcpyAsync(&h, w.rows_max, sizeof h, hipMemcpyDeviceToHost, stream));
-    RT_HIP(hipStreamSynchronize(stream));
-    RT_REQUIRE((uint64_t)h < (uint64_t)p->height * p->n_frames, RT_ERR_INVALID, "rt_render_device: row id out of range");
+    RT_HIP(hipMemcpyAsync(w.h_rows_max, w.rows_max, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+}
+void end_check_device_rows(Workspace &w, const rt_params *p) {      // (after a synchronisation of the stream)
+    if (p->n_rows == 0) return;
+    RT_REQUIRE((uint64_t)*w.h_rows_max < (uint64_t)p->height * p->n_frames, RT_ERR_INVALID, "rt_render_device: row id out of range");
 }
 
 // Enqueue one render on `stream`; row ids and output are device pointers.
 void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint32_t *d_rows, double *d_out,
-             hipStream_t stream, rt_stats *stats) {
+             hipStream_t stream, rt_stats *stats, bool check_rows = false /* the row ids came from the caller's HBM: range-check them */) {
     Workspace &w = workspace_for(sc, stream);
     RenderArgs a{};
     a.cam = *cam;
@@ -494,7 +503,9 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
         if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
         RT_HIP(hipMemcpyAsync(w.d_args, &a, sizeof(RenderArgs), hipMemcpyHostToDevice, stream));
+        if (check_rows) begin_check_device_rows(w, p, stream);
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
+        if (check_rows) end_check_device_rows(w, p);
         RT_HIP(hipEventRecord(w.ev0, stream));
         if (a.n_items > 0) {
             uint32_t fault = 0;
@@ -524,6 +535,11 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         w.tape_bytes = tape_bytes;
     }
     a.tape = w.tape;
+    if (check_rows) {                              // (the A/B engine enqueues without a synchronisation of its own)
+        begin_check_device_rows(w, p, stream);
+        RT_HIP(hipStreamSynchronize(stream));
+        end_check_device_rows(w, p);
+    }
     RT_HIP(hipMemsetAsync(w.work_counter, 0, sizeof(unsigned long long), stream));
     if (counters) RT_HIP(hipMemsetAsync(w.stats, 0, sizeof(StatsDev), stream));
     RT_HIP(hipEventRecord(w.ev0, stream));
@@ -713,6 +729,7 @@ int rt_scene_destroy(rt_scene *scene) {
         for (auto &kv : scene->ws) {
             Workspace &w = kv.second;
             if (w.rows_max) (void)hipFree(w.rows_max);
+            if (w.h_rows_max) (void)hipHostFree(w.h_rows_max);
             for (hipEvent_t ev : w.kt.ev) (void)hipEventDestroy(ev);
             if (w.work_counter) (void)hipFree(w.work_counter);
             if (w.stats) (void)hipFree(w.stats);
@@ -742,8 +759,7 @@ int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *par
         check_params(scene, cam, params);
         RT_REQUIRE(d_out_rgb_sum || params->n_rows == 0, RT_ERR_INVALID, "rt_render_device: output is null");
         DeviceGuard guard(scene->device);
-        check_device_rows(workspace_for(scene, (hipStream_t)hip_stream), params, (hipStream_t)hip_stream);
-        enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, (hipStream_t)hip_stream, stats);
+        enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, (hipStream_t)hip_stream, stats, true);
         return RT_OK;
     });
 }
@@ -1003,6 +1019,71 @@ int rt_debug_traffic_probe(int mode, uint64_t buffer_bytes, uint64_t n_access, u
         } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
         if (buf) (void)hipFree(buf);
         if (sink) (void)hipFree(sink);
+        return rc;
+    });
+}
+
+} // extern "C"
+
+// ---- VALU counter calibration (tools/valu_calib.sh) ------------------------------------------------------------------
+// What do SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_THREAD_CYCLES_VALU / SQ_BUSY_CYCLES read for a kernel whose vector
+// pipes are KNOWN to be saturated? These kernels issue nothing but independent vector instructions of one kind at 8
+// waves per SIMD on every CU, so their issue-slot occupancy is 1 by construction; the counters read under rocprofv3 give
+// the normalisation bench.py uses to turn the traversal kernel's counters into a measured busy fraction.
+namespace {
+// MODE 0: v_fma_f64, all lanes; 1: 32-bit integer VALU (v_add / v_xor), all lanes; 2: v_fma_f64 with half the lanes
+// switched off (EXEC = low 32 lanes); 3: four f64 and four 32-bit instructions alternating; 4: v_fma_f64 at ONE wave per SIMD.
+template <int MODE>
+__global__ void __launch_bounds__(256) valu_probe_kernel(double *out, uint32_t iters, double b, double c, uint32_t k) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    double a0 = (double)gid, a1 = a0 + 1.0, a2 = a0 + 2.0, a3 = a0 + 3.0, a4 = a0 + 4.0, a5 = a0 + 5.0, a6 = a0 + 6.0, a7 = a0 + 7.0;
+    uint32_t x0 = gid, x1 = gid + 1u, x2 = gid + 2u, x3 = gid + 3u, x4 = gid + 4u, x5 = gid + 5u, x6 = gid + 6u, x7 = gid + 7u;
+    const bool on = MODE != 2 || (threadIdx.x & 63u) < 32u;
+    if (on) {
+        for (uint32_t i = 0; i < iters; i++) {
+            if (MODE == 0 || MODE == 2 || MODE == 4) {
+                a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c);
+                a4 = __builtin_fma(a4, b, c); a5 = __builtin_fma(a5, b, c); a6 = __builtin_fma(a6, b, c); a7 = __builtin_fma(a7, b, c);
+            } else if (MODE == 1) {
+                x0 = (x0 + k) ^ x4; x1 = (x1 + k) ^ x5; x2 = (x2 + k) ^ x6; x3 = (x3 + k) ^ x7;
+                x4 = (x4 + k) ^ x0; x5 = (x5 + k) ^ x1; x6 = (x6 + k) ^ x2; x7 = (x7 + k) ^ x3;
+            } else {
+                a0 = __builtin_fma(a0, b, c); x0 = (x0 + k) ^ x4; a1 = __builtin_fma(a1, b, c); x1 = (x1 + k) ^ x5;
+                a2 = __builtin_fma(a2, b, c); x2 = (x2 + k) ^ x6; a3 = __builtin_fma(a3, b, c); x3 = (x3 + k) ^ x7;
+            }
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));   // (no folding of the loop)
+        }
+    }
+    out[gid] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7);
+}
+} // namespace
+
+extern "C" {
+
+int rt_debug_valu_probe(int mode, uint32_t iters) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(mode >= 0 && mode <= 4 && iters > 0, RT_ERR_INVALID, "rt_debug_valu_probe: bad arguments");
+        int dev = 0, cus = 0;
+        RT_HIP(hipGetDevice(&dev));
+        RT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const uint32_t blocks = (uint32_t)cus * (mode == 4 ? 1u : 8u);       // 8 workgroups of 4 waves per CU = 8 waves per SIMD (mode 4: one)
+        double *out = nullptr;
+        int rc = RT_OK;
+        try {
+            RT_HIP(hipMalloc((void **)&out, (uint64_t)blocks * 256 * sizeof(double)));
+            const double b = 0.9999999, c = 1e-9;
+            const uint32_t k = 0x9E3779B9u;
+            switch (mode) {
+                case 0: hipLaunchKernelGGL((valu_probe_kernel<0>), dim3(blocks), dim3(256), 0, nullptr, out, iters, b, c, k); break;
+                case 1: hipLaunchKernelGGL((valu_probe_kernel<1>), dim3(blocks), dim3(256), 0, nullptr, out, iters, b, c, k); break;
+                case 2: hipLaunchKernelGGL((valu_probe_kernel<2>), dim3(blocks), dim3(256), 0, nullptr, out, iters, b, c, k); break;
+                case 3: hipLaunchKernelGGL((valu_probe_kernel<3>), dim3(blocks), dim3(256), 0, nullptr, out, iters, b, c, k); break;
+                default: hipLaunchKernelGGL((valu_probe_kernel<4>), dim3(blocks), dim3(256), 0, nullptr, out, iters, b, c, k); break;
+            }
+            RT_HIP(hipGetLastError());
+            RT_HIP(hipDeviceSynchronize());
+        } catch (const Fail &e) { set_error(e.msg); rc = e.code; }
+        if (out) (void)hipFree(out);
         return rc;
     });
 }

@@ -196,6 +196,7 @@ bool jpeg_decode_rgb8(const uint8_t *data, size_t size, uint32_t &width, uint32_
             while (seg < seg_end) {
                 int pq = seg[0] >> 4, tq = seg[0] & 15;
                 if (tq > 3 || pq > 1) return fail("bad DQT");
+                if (pq == 1) return fail("16-bit quantisation tables are not supported (8-bit baseline files use 8-bit tables)");
                 seg++;
                 if (seg + (pq ? 128 : 64) > seg_end) return fail("truncated DQT");
                 for (int i = 0; i < 64; i++) { qt[tq][kZigzag[i]] = pq ? (uint16_t)be16(seg + 2 * i) : seg[i]; }
@@ -218,6 +219,8 @@ bool jpeg_decode_rgb8(const uint8_t *data, size_t size, uint32_t &width, uint32_
             height = be16(seg + 1); width = be16(seg + 3);
             int nc = seg[5];
             if (width == 0 || height == 0 || (nc != 1 && nc != 3) || seg + 6 + 3 * nc > seg_end) return fail("unsupported frame header");
+            // (the planes and the RGB image are allocated from these two header fields alone: 2^28 pixels = 805 MB of RGB at most)
+            if ((uint64_t)width * height > (1ull << 28)) return fail("image larger than 2^28 pixels");
             comps.resize((size_t)nc);
             for (int i = 0; i < nc; i++) {
                 Component &c = comps[(size_t)i];
@@ -233,6 +236,7 @@ bool jpeg_decode_rgb8(const uint8_t *data, size_t size, uint32_t &width, uint32_
             restart_interval = (int)be16(seg);
         } else if (m == 0xDA) {                                                // SOS: the one scan of a baseline file
             if (!have_frame) return fail("SOS before SOF");
+            if (seg >= seg_end) return fail("empty SOS header");
             int ns = seg[0];
             if (ns != (int)comps.size() || seg + 1 + 2 * ns + 3 > seg_end) return fail("scan does not cover all components");
             for (int i = 0; i < ns; i++) {
@@ -269,6 +273,8 @@ bool jpeg_decode_rgb8(const uint8_t *data, size_t size, uint32_t &width, uint32_
                                 if (t < 0 || t > 11) return fail("bad DC code");
                                 int diff = t ? extend(br.bits(t), t) : 0;
                                 c.dc_pred += diff;
+                                // (a conforming stream keeps the predictor inside 16 bits; a hostile one may not: no overflow either way)
+                                if (c.dc_pred < -32768 || c.dc_pred > 32767) return fail("DC predictor out of range");
                                 coef[0] = c.dc_pred * (int)qt[c.tq][0];
                                 for (int k = 1; k < 64;) {
                                     int rs = decode_symbol(br, hac[c.ta]);

@@ -137,3 +137,24 @@ def test_jpeg_writer_round_trip(rt, tmp_path):
         pass
     rt.write_jpeg(path, img, 50)
     assert os.path.getsize(path) < img.size and np.abs(rt.load_image(path).astype(np.int32) - img).mean() < 40
+
+
+def test_jpeg_parser_refuses_hostile_headers(rt, tmp_path):
+    """asset files come from the user. A scan header cut off at the end of the file, 16-bit quantisation
+    tables in an 8-bit file and dimensions that would allocate gigabytes from two header fields are all errors,
+    never reads past the buffer, integer overflow or a 12 GB allocation."""
+    def seg(marker, payload):
+        return b"\xff" + bytes([marker]) + (len(payload) + 2).to_bytes(2, "big") + payload
+    soi, eoi = b"\xff\xd8", b"\xff\xd9"
+    dqt8 = seg(0xDB, b"\x00" + bytes([1] * 64))
+    sof = lambda w, h: seg(0xC0, b"\x08" + h.to_bytes(2, "big") + w.to_bytes(2, "big") + b"\x01" + b"\x01\x11\x00")
+    cases = {
+        "sos_len2.jpg": (soi + dqt8 + sof(8, 8) + b"\xff\xda\x00\x02", "empty SOS"),         # SOS whose payload is empty, at the very end
+        "dqt16.jpg": (soi + seg(0xDB, b"\x10" + bytes([0, 1] * 64)) + sof(8, 8) + eoi, "16-bit quantisation"),    # pq = 1
+        "huge.jpg": (soi + dqt8 + sof(65535, 65535) + eoi, "image larger than"),             # 4.3 G pixels from the header alone
+    }
+    for name, (blob, why) in cases.items():
+        path = tmp_path / name
+        path.write_bytes(blob)
+        with pytest.raises(rt.RtError, match=why):
+            rt.load_image(str(path))
