@@ -52,7 +52,7 @@ int rt_debug_pass_timing(const rt_scene *scene, double out[5]);
  * Run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/traffic_calib.sh). */
 int rt_debug_traffic_probe(int mode, uint64_t buffer_bytes, uint64_t n_access, uint64_t seed);
 /* VALU counter calibration: a kernel whose vector pipes are saturated by construction — nothing but independent
- * vector instructions of one kind, 8 waves per SIMD on every CU, `iters` rounds of 8 of them per lane. mode 0 v_fma_f64,
+ * vector instructions of one kind, 8 waves per SIMD on every CU, `iters` rounds of 64 of them per lane. mode 0 v_fma_f64,
  * 1 32-bit integer add / xor, 2 v_fma_f64 with half of every wave's lanes switched off, 3 f64 and 32-bit alternating,
  * 4 v_fma_f64 at one wave per SIMD. Run under rocprofv3 --pmc (tools/valu_calib.sh): what the SQ counters read for
  * it is the normalisation bench.py turns the traversal kernel's counters into a busy fraction with. */

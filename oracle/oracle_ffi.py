@@ -22,11 +22,15 @@ class rto_hit_record(C.Structure):
                 ("t", C.c_double), ("u", C.c_double), ("v", C.c_double), ("mat", C.c_uint32), ("rng_draws", C.c_uint32)]
 
 
-def build():
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+LIBM_LIB_PATH = os.path.join(_HERE, "librt_oracle_libm.so")
+
+
+def build(target=None):
+    subprocess.check_call(["make", "-s", "-C", _HERE] + ([target] if target else []))
 
 
 _lib = None
+_lib_libm = None
 
 
 def lib():
@@ -35,7 +39,24 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def lib_libm():
+    """The -DRTO_LIBM build of the same restatement: the render path's sin / cos / acos / atan2 / log are the
+    platform libm's (what the Rust reference links), not rt_math.h's. For tools/libm_sensitivity.py only."""
+    global _lib_libm
+    if _lib_libm is not None:
+        return _lib_libm
+    if not os.path.exists(LIBM_LIB_PATH):
+        build("libm")
+    _lib_libm = _bind(C.CDLL(LIBM_LIB_PATH))
+    assert _lib_libm.rto_uses_libm() == 1 and lib().rto_uses_libm() == 0
+    return _lib_libm
+
+
+def _bind(L):
     P, dbl, u64, u32 = C.POINTER, C.c_double, C.c_uint64, C.c_uint32
     L.rt_render_cpu.argtypes = [P(F.rt_scene_desc), P(F.rt_camera), P(F.rt_params), P(dbl), P(F.rt_stats), C.c_int]
     L.rto_write_color.argtypes = [P(dbl), C.c_int32, P(C.c_uint8)]
@@ -65,7 +86,9 @@ def lib():
         f.restype = None
     L.rto_path_key.argtypes = [u64, u32, u64, u32]
     L.rto_path_key.restype = u64
-    _lib = L
+    L.rto_uses_libm.restype = C.c_int
+    L.rto_path_math.argtypes = [C.c_int, dbl, dbl]
+    L.rto_path_math.restype = dbl
     return L
 
 
@@ -73,18 +96,19 @@ def _d(v):
     return (C.c_double * len(v))(*[float(x) for x in v])
 
 
-def render_cpu(desc, cam, params, row_ids, n_threads=1, want_stats=False):
-    """rt_render_cpu → (n_rows, width, 3) float64 sums [, rt_stats]."""
+def render_cpu(desc, cam, params, row_ids, n_threads=1, want_stats=False, libm=False):
+    """rt_render_cpu → (n_rows, width, 3) float64 sums [, rt_stats]. libm=True: the -DRTO_LIBM build (lib_libm)."""
+    L = lib_libm() if libm else lib()
     rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
     p = F.rt_params.from_buffer_copy(params)
     p.n_rows = len(rows)
     p.row_ids = rows.ctypes.data
     out = np.empty((len(rows), p.width, 3), dtype=np.float64)
     st = F.rt_stats()
-    rc = lib().rt_render_cpu(C.byref(desc), C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)),
-                             C.byref(st), n_threads)
+    rc = L.rt_render_cpu(C.byref(desc), C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)),
+                         C.byref(st), n_threads)
     if rc < 0:
-        raise RuntimeError("oracle error %d: %s" % (rc, lib().rto_last_error().decode()))
+        raise RuntimeError("oracle error %d: %s" % (rc, L.rto_last_error().decode()))
     return (out, st) if want_stats else out
 
 

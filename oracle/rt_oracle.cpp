@@ -17,6 +17,7 @@
 // JPEG/OBJ decoding are "parity unpinned" (third-party crates absent).
 //
 // Reference: /root/reference/raytracer/src (cited as file:line).
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -32,6 +33,29 @@
 using rtm::Ray;
 using rtm::Rng;
 using rtm::Vec3;
+
+// The five transcendentals of the render path (sphere.rs:30-34, constantmedium.rs:61, texture/mod.rs:52,77,
+// pdf.rs:15-18, vec.rs:112-115). Default build: the fdlibm restatements of rt_math.h, shared with the device so that
+// HIP == oracle bit for bit. -DRTO_LIBM (librt_oracle_libm.so, `make libm`): the platform libm — what the Rust
+// reference itself links (f64::sin/cos/acos/atan2/ln are libm calls) — so that tools/libm_sensitivity.py can measure
+// what the <= 1 ulp between the two does to a pixel. That build shares NO transcendental with the product.
+namespace om {
+#ifdef RTO_LIBM
+inline double sin_(double x) { return ::sin(x); }
+inline double cos_(double x) { return ::cos(x); }
+inline double acos_(double x) { return ::acos(x); }
+inline double atan2_(double y, double x) { return ::atan2(y, x); }
+inline double log_(double x) { return ::log(x); }
+constexpr int kLibm = 1;
+#else
+inline double sin_(double x) { return rtm::sin_(x); }
+inline double cos_(double x) { return rtm::cos_(x); }
+inline double acos_(double x) { return rtm::acos_(x); }
+inline double atan2_(double y, double x) { return rtm::atan2_(y, x); }
+inline double log_(double x) { return rtm::log_(x); }
+constexpr int kLibm = 0;
+#endif
+} // namespace om
 typedef Vec3 Color;
 typedef Vec3 Point3;
 
@@ -95,8 +119,8 @@ bool node_hit(Ctx &c, const rt_bvh_node &n, const Ray &r, double t_min, double t
 
 // ---- get_sphere_uv, hittable/sphere.rs:30-34 ---------------------------------
 void sphere_uv(Point3 p, double &u, double &v) {
-    double theta = rtm::acos_(-p.y);
-    double phi = rtm::atan2_(-p.z, p.x) + rtm::PI;
+    double theta = om::acos_(-p.y);
+    double phi = om::atan2_(-p.z, p.x) + rtm::PI;
     u = phi / (2.0 * rtm::PI);
     v = theta / rtm::PI;
 }
@@ -230,7 +254,7 @@ bool medium_hit(Ctx &c, const rt_medium &m, const Ray &r, double t_min, double t
     double ray_length = r.dir.length();
     double distance_inside_boundary = (rec2.t - rec1.t) * ray_length;
     double rnd = c.rng->gen_f64();
-    double hit_distance = m.neg_inv_density * (rtm::log_(rnd) / rtm::log_(rtm::E_));   // rnd.log(E)
+    double hit_distance = m.neg_inv_density * (om::log_(rnd) / om::log_(rtm::E_));   // rnd.log(E)
     if (hit_distance > distance_inside_boundary) return false;
     rec.p = r.at(rec1.t + hit_distance / ray_length);
     rec.normal = Vec3(1.0, 0.0, 0.0);
@@ -371,11 +395,11 @@ Color texture_value(const rt_scene_desc &s, uint32_t tex, double u, double v, Po
     switch (t.kind) {
         case RT_TEX_SOLID: return v3(t.color);
         case RT_TEX_CHECKER: {                                     // mod.rs:51-60
-            double sines = rtm::sin_(p.x * 10.0) * rtm::sin_(p.y * 10.0) * rtm::sin_(p.z * 10.0);
+            double sines = om::sin_(p.x * 10.0) * om::sin_(p.y * 10.0) * om::sin_(p.z * 10.0);
             return sines < 0.0 ? texture_value(s, t.a, u, v, p) : texture_value(s, t.b, u, v, p);
         }
         case RT_TEX_NOISE: {                                       // mod.rs:75-79
-            double k = 1.0 + rtm::sin_(t.scale * p.z + 10.0 * perlin_turb(s.perlins[t.a], p, 7));
+            double k = 1.0 + om::sin_(t.scale * p.z + 10.0 * perlin_turb(s.perlins[t.a], p, 7));
             return Color(1.0, 1.0, 1.0) * 0.5 * k;
         }
         default: {                                                 // mod.rs:110-139
@@ -418,8 +442,8 @@ Vec3 random_to_sphere(Rng &rng, double radius, double dis_sqr) {
     double r2 = rng.gen_f64();
     double z = 1.0 + r2 * (rtm::sqrt_(1.0 - radius * radius / dis_sqr) - 1.0);
     double phi = 2.0 * rtm::PI * r1;
-    double x = rtm::cos_(phi) * rtm::sqrt_(1.0 - z * z);
-    double y = rtm::sin_(phi) * rtm::sqrt_(1.0 - z * z);
+    double x = om::cos_(phi) * rtm::sqrt_(1.0 - z * z);
+    double y = om::sin_(phi) * rtm::sqrt_(1.0 - z * z);
     return Vec3(x, y, z);
 }
 Vec3 random_cosine_direction(Rng &rng) {
@@ -427,8 +451,8 @@ Vec3 random_cosine_direction(Rng &rng) {
     double r2 = rng.gen_f64();
     double z = rtm::sqrt_(1.0 - r2);
     double phi = 2.0 * rtm::PI * r1;
-    double x = rtm::cos_(phi) * rtm::sqrt_(r2);
-    double y = rtm::sin_(phi) * rtm::sqrt_(r2);
+    double x = om::cos_(phi) * rtm::sqrt_(r2);
+    double y = om::sin_(phi) * rtm::sqrt_(r2);
     return Vec3(x, y, z);
 }
 
@@ -811,6 +835,19 @@ double rto_math(int op, double a, double b) {
         case RTO_SQRT: return rtm::sqrt_(a);
         case RTO_DIV: return a / b;
         default: return 0.0;
+    }
+}
+// 1: this library was built with -DRTO_LIBM (the render path's transcendentals are the platform libm's).
+int rto_uses_libm(void) { return om::kLibm; }
+// The transcendentals AS THE RENDER PATH OF THIS BUILD CALLS THEM (rto_math above is always rt_math.h).
+double rto_path_math(int op, double a, double b) {
+    switch (op) {
+        case RTO_SIN: return om::sin_(a);
+        case RTO_COS: return om::cos_(a);
+        case RTO_ACOS: return om::acos_(a);
+        case RTO_ATAN2: return om::atan2_(a, b);
+        case RTO_LOG: return om::log_(a);
+        default: return rto_math(op, a, b);
     }
 }
 void rto_math_array(int op, const double *a, const double *b, double *out, uint64_t n) {

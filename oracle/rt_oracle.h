@@ -38,6 +38,10 @@ int rto_lights_random(const rt_scene_desc *scene, const double o[3], uint64_t rn
 int rto_scatter(const rt_scene_desc *scene, uint32_t mat, const double ray_in[7], const rto_hit_record *rec_in,
                 uint64_t rng_state, double out_ray[7], double out_attenuation[3], double out_emitted[3]);
 double rto_math(int op, double a, double b);
+/* 1 if this library was built with -DRTO_LIBM (`make libm`: the render path calls the platform libm). */
+int rto_uses_libm(void);
+/* The transcendental as the render path of THIS build calls it (rt_math.h, or the platform libm under -DRTO_LIBM). */
+double rto_path_math(int op, double a, double b);
 void rto_math_array(int op, const double *a, const double *b, double *out, uint64_t n);
 void rto_rng_u64(uint64_t state, uint64_t *out, uint64_t n);
 void rto_rng_f64(uint64_t state, double *out, uint64_t n);

@@ -1041,6 +1041,8 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(double *out, uint32_t i
     const bool on = MODE != 2 || (threadIdx.x & 63u) < 32u;
     if (on) {
         for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+          for (int rep = 0; rep < 8; rep++) {                // (64 vector instructions between two loop branches)
             if (MODE == 0 || MODE == 2 || MODE == 4) {
                 a0 = __builtin_fma(a0, b, c); a1 = __builtin_fma(a1, b, c); a2 = __builtin_fma(a2, b, c); a3 = __builtin_fma(a3, b, c);
                 a4 = __builtin_fma(a4, b, c); a5 = __builtin_fma(a5, b, c); a6 = __builtin_fma(a6, b, c); a7 = __builtin_fma(a7, b, c);
@@ -1052,6 +1054,7 @@ __global__ void __launch_bounds__(256) valu_probe_kernel(double *out, uint32_t i
                 a2 = __builtin_fma(a2, b, c); x2 = (x2 + k) ^ x6; a3 = __builtin_fma(a3, b, c); x3 = (x3 + k) ^ x7;
             }
             asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));   // (no folding of the loop)
+          }
         }
     }
     out[gid] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7);

@@ -7,7 +7,7 @@ shift
 i=0
 for st in "${settings[@]}"; do
   i=$((i+1))
-  env $st timeout -k 10 300 python bench.py --no-cpu-baseline --no-pmc "$@" > gpurun_out/abenv_$i.log 2>&1 || { echo "[$st]: bench failed, stopping"; tail -3 gpurun_out/abenv_$i.log; exit 1; }
+  env $st timeout -k 10 300 python bench.py --no-cpu-baseline --no-pmc --no-plain "$@" > gpurun_out/abenv_$i.log 2>&1 || { echo "[$st]: bench failed, stopping"; tail -3 gpurun_out/abenv_$i.log; exit 1; }
   python3 - "$st" gpurun_out/abenv_$i.log <<'PY'
 import sys, json
 n, f = sys.argv[1], sys.argv[2]

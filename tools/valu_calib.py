@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_2022_amd import _ffi as F
-ITERS = 100000
+ITERS = 12500          # x 64 vector instructions per lane
 for mode in range(5):
     F.check(F.lib().rt_debug_valu_probe(mode, ITERS))
 print("ok")
