@@ -15,6 +15,22 @@
 
 using namespace rt2022;
 
+// The per-worker bar of main.rs:102-127,154-155 (indicatif: "[{elapsed_precise}] [{bar:40}] ({eta})"), redrawn in place from the
+// library's progress callback: camera paths started / total for the one worker a single-GPU rt_render has.
+static void progress_bar(void *user, uint32_t worker, uint64_t done, uint64_t total) {
+    const auto *begin = static_cast<const std::chrono::steady_clock::time_point *>(user);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - *begin).count();
+    const double share = total ? (double)done / (double)total : 1.0;
+    char bar[41];
+    const int fill = (int)(40.0 * share);
+    for (int i = 0; i < 40; i++) bar[i] = i < fill ? '#' : (i == fill ? '>' : '-');
+    bar[40] = 0;
+    const double eta = share > 0.0 ? secs * (1.0 - share) / share : 0.0;
+    std::fprintf(stderr, "\r  GPU %u [%02d:%02d] [%s] %5.1f %% (eta %.1f s) ", worker, (int)secs / 60, (int)secs % 60, bar, 100.0 * share, eta);
+    if (done == total) std::fprintf(stderr, "\n");
+    std::fflush(stderr);
+}
+
 int main(int argc, char **argv) {
     // Image (main.rs:33-41)
     const std::string scene_name = argc > 1 ? argv[1] : "cornell_box";
@@ -69,6 +85,9 @@ int main(int argc, char **argv) {
         p.n_rows = IMAGE_HEIGHT; p.row_ids = random_line_id.data();
         p.spp_chunk = 1;    // one work item per sample: the reference's running sum per pixel bit for bit (like 0), but parallel
         p.flags = 0;
+        auto render_begin = std::chrono::steady_clock::now();
+        p.progress_cb = progress_bar;                // main.rs:124-127,154-155
+        p.progress_user = &render_begin;
         std::vector<double> output_pixel_color((size_t)IMAGE_WIDTH * IMAGE_HEIGHT * 3);
         rt_stats stats{};
         if (rt_render(scene, &cam.c, &p, output_pixel_color.data(), &stats) != RT_OK) {

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RT2022_ABI_VERSION 2
+#define RT2022_ABI_VERSION 3
 
 /* ---------------------------------------------------------------- refs --- */
 /* A hittable reference = one `Arc<dyn Hittable>` of the reference, as a tagged
@@ -260,6 +260,14 @@ typedef struct rt_params {
      * the finest work items: what a throughput-minded caller should pass. */
     uint32_t spp_chunk;
     uint32_t flags;                   /* RT_FLAG_* */
+    /* Per-worker progress (the indicatif bars of main.rs:102-127,154-155: one per render thread, advanced as its rows
+     * finish). NULL = none. Called on the thread that called rt_render* (rt_render_multi: on the device's own host
+     * thread, concurrently with the other devices' — `worker` is the device's place in the set, 0 otherwise), between
+     * passes — every few milliseconds of device time — with the camera paths started so far and their total
+     * (n_rows * width * spp), and once more with done == total when the call's last pass has completed. It must
+     * not call back into the library on the same scene; it never affects results. */
+    void (*progress_cb)(void *user, uint32_t worker, uint64_t paths_done, uint64_t paths_total);
+    void *progress_user;
 } rt_params;
 
 #define RT_FLAG_COUNTERS 0x1u         /* fill the counter fields of rt_stats */

@@ -7,7 +7,7 @@ library has not been built — there is no Python or CPU fallback for the path.
 import ctypes as C
 import os
 
-RT2022_ABI_VERSION = 2
+RT2022_ABI_VERSION = 3
 
 RT_REF_FLIP = 0x80000000
 RT_REF_KIND_SHIFT = 27
@@ -130,7 +130,12 @@ class rt_params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
                 ("background", d3), ("t_min", C.c_double), ("seed", C.c_uint64),
                 ("n_frames", C.c_uint32), ("n_rows", C.c_uint32), ("row_ids", C.c_void_p),
-                ("spp_chunk", C.c_uint32), ("flags", C.c_uint32)]
+                ("spp_chunk", C.c_uint32), ("flags", C.c_uint32),
+                ("progress_cb", C.c_void_p), ("progress_user", C.c_void_p)]
+
+
+# void (*progress_cb)(void *user, uint32_t worker, uint64_t paths_done, uint64_t paths_total)
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)
 
 
 class rt_stats(C.Structure):

@@ -198,6 +198,14 @@ struct WfStreams {
     hipStream_t stream[kMaxGroups] = {};
     hipEvent_t ev[kMaxGroups][2] = {};
     uint32_t *h_active = nullptr;      // pinned, [kMaxGroups][2]
+    unsigned long long *h_work = nullptr;   // pinned, [kMaxGroups][2]: the work counter as of the same batches (progress callback)
+};
+// rt_params::progress_cb as the engine sees it (host side only).
+struct Progress {
+    void (*cb)(void *, uint32_t, uint64_t, uint64_t) = nullptr;
+    void *user = nullptr;
+    uint64_t total = 0;                // camera paths of the call
+    uint32_t per_item = 1;             // samples per work item
 };
 // Per-kernel device time of one render (RT_FLAG_KERNEL_TIMES): HIP events on the launch stream around every pass.
 struct KernelTimes {
@@ -211,7 +219,8 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                                    const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations,
                                    double *timing /* null, or [5]: see rt_debug_pass_timing */,
                                    uint32_t *out_fault /* WfPool::fault after the last pass */,
-                                   KernelTimes *kt /* null, or where to put the per-kernel times (forces one group) */);
+                                   KernelTimes *kt /* null, or where to put the per-kernel times (forces one group) */,
+                                   const Progress *progress = nullptr);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);

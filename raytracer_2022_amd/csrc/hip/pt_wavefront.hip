@@ -1628,8 +1628,11 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
 // with one group: the mean wave lives 0.41 of a trace pass — rt_debug_pass_timing.)
 static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                 const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
-                                const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing, KernelTimes *kt) {
+                                const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing, KernelTimes *kt,
+                                const Progress *progress) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
+    const bool report = progress && progress->cb && gs.h_work;
+    unsigned long long reported = 0;
     const uint32_t blocks = pool.n_blocks;
     hipError_t e;
     // Slots in use start FRESH (at most one work item per slot is ever needed at a time).
@@ -1701,6 +1704,8 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         const uint32_t b = batches[g]++ & 1u;   // ring of two: batches of a group complete in order
         if ((e = hipMemcpyAsync(gs.h_active + 2 * g + b, w[g].pool.n_active + ((iter[g] - 1) & 1u), sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
+        if (report && (e = hipMemcpyAsync(gs.h_work + 2 * g + b, args.work_counter, sizeof(unsigned long long),
+                                          hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
         return hipEventRecord(gs.ev[g][b], w[g].stream);
     };
     uint32_t waited[kMaxGroups] = {};           // batches whose answer has been read
@@ -1715,6 +1720,13 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
             const uint32_t b = waited[g] & 1u;
             if ((e = hipEventSynchronize(gs.ev[g][b])) != hipSuccess) return e;
             waited[g]++;
+            if (report) {                       // work items handed out so far -> camera paths started (main.rs:154-155: the bar's inc)
+                unsigned long long items = gs.h_work[2 * g + b];
+                if (items > args.n_items) items = args.n_items;       // (the counter overshoots at the end of the work)
+                unsigned long long paths = items * progress->per_item;
+                if (paths > progress->total) paths = progress->total;
+                if (paths > reported && paths < progress->total) { reported = paths; progress->cb(progress->user, 0u, paths, progress->total); }
+            }
             if (timing) {
                 unsigned long long h[5];
                 if ((e = hipMemcpy(h, pool.dbg, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess) return e;
@@ -1788,8 +1800,8 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                    const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing,
-                                   uint32_t *out_fault, KernelTimes *kt) {
-    hipError_t e = render_passes(scene, args, d_args, pool, stack_need, features, counters, gs, stream, out_iterations, timing, kt);
+                                   uint32_t *out_fault, KernelTimes *kt, const Progress *progress) {
+    hipError_t e = render_passes(scene, args, d_args, pool, stack_need, features, counters, gs, stream, out_iterations, timing, kt, progress);
     if (e != hipSuccess) {
         // Passes may still be queued or running against the pool on the group streams: let them finish (best
         // effort) before the caller sees the error and possibly frees or reuses the pool.

@@ -355,6 +355,7 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
         RT_HIP(hipMalloc((void **)&w.d_args, sizeof(RenderArgs)));
         RT_HIP(hipMalloc((void **)&w.d_pool, sizeof(WfPool)));
         RT_HIP(hipHostMalloc((void **)&w.gs.h_active, 2 * kMaxGroups * sizeof(uint32_t)));
+        RT_HIP(hipHostMalloc((void **)&w.gs.h_work, 2 * kMaxGroups * sizeof(unsigned long long)));
         for (int g = 0; g < kMaxGroups; g++) {
             RT_HIP(hipStreamCreateWithFlags(&w.gs.stream[g], hipStreamNonBlocking));
             for (int b = 0; b < 2; b++) RT_HIP(hipEventCreateWithFlags(&w.gs.ev[g][b], hipEventDisableTiming));
@@ -507,10 +508,13 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         RT_HIP(hipStreamSynchronize(stream));      // the three structs above live on this thread's stack
         if (check_rows) end_check_device_rows(w, p);
         RT_HIP(hipEventRecord(w.ev0, stream));
+        Progress prog;
+        prog.cb = p->progress_cb; prog.user = p->progress_user;
+        prog.total = a.n_pixels * p->spp; prog.per_item = a.chunk;
         if (a.n_items > 0) {
             uint32_t fault = 0;
             RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.gs, stream, &w.iterations,
-                                           timing ? sc->pass_timing : nullptr, &fault, want_kt ? &w.kt : nullptr));
+                                           timing ? sc->pass_timing : nullptr, &fault, want_kt ? &w.kt : nullptr, &prog));
             RT_REQUIRE(fault == 0, RT_ERR_DEVICE, "wavefront engine: a path slot reached the shade pass without having been traced (internal error; the frame is incomplete)");
             if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
@@ -519,6 +523,8 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         w.pending_counters = counters;
         w.used_chunk = a.chunk; w.used_passes = w.iterations; w.used_slots = (uint64_t)w.pool.n_blocks * kSlotsPerBlock;
         w.used_kt = want_kt && a.n_items > 0;
+        // (every pass of the frame has been issued and observed: the render is complete up to the chunk sums queued behind it)
+        if (prog.cb) prog.cb(prog.user, 0u, prog.total, prog.total);
         return;
     }
     // Megakernel engine. Bounce tape: max_depth records of 4 doubles for every lane of the persistent grid.
@@ -551,6 +557,10 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     w.pending = stats;
     w.pending_counters = counters;
     w.used_chunk = a.chunk; w.used_passes = 0; w.used_slots = 0; w.used_kt = false;
+    if (p->progress_cb) {                          // (the A/B engine is one launch: nothing to report in between)
+        RT_HIP(hipStreamSynchronize(stream));
+        p->progress_cb(p->progress_user, 0u, a.n_pixels * p->spp, a.n_pixels * p->spp);
+    }
 }
 
 void finish(rt_scene *sc, hipStream_t stream) {
@@ -740,6 +750,7 @@ int rt_scene_destroy(rt_scene *scene) {
             if (w.d_args) (void)hipFree(w.d_args);
             if (w.d_pool) (void)hipFree(w.d_pool);
             if (w.gs.h_active) (void)hipHostFree(w.gs.h_active);
+            if (w.gs.h_work) (void)hipHostFree(w.gs.h_work);
             for (int g = 0; g < kMaxGroups; g++) {
                 if (w.gs.stream[g]) (void)hipStreamDestroy(w.gs.stream[g]);
                 for (int b = 0; b < 2; b++) if (w.gs.ev[g][b]) (void)hipEventDestroy(w.gs.ev[g][b]);
@@ -873,6 +884,12 @@ int rt_render_multi(rt_scene_set *set, const rt_camera *cam, const rt_params *pa
                 rt_params p = *params;
                 p.n_rows = (uint32_t)sh.rows.size();
                 p.row_ids = sh.rows.data();
+                // per-worker progress: this device's share under its place in the set (main.rs:124-127: one bar per thread)
+                struct Relay { void (*cb)(void *, uint32_t, uint64_t, uint64_t); void *user; uint32_t worker; } relay{params->progress_cb, params->progress_user, (uint32_t)k};
+                if (params->progress_cb) {
+                    p.progress_user = &relay;
+                    p.progress_cb = [](void *u, uint32_t, uint64_t done, uint64_t total) { const Relay *r = static_cast<const Relay *>(u); r->cb(r->user, r->worker, done, total); };
+                }
                 sh.out.resize(sh.rows.size() * row_doubles);
                 // (rt_render makes the scene's device current for this thread and leaves the caller's alone)
                 sh.rc = rt_render(set->scenes[k], cam, &p, sh.out.data(), &sh.st);

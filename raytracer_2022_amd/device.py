@@ -44,14 +44,18 @@ class DeviceScene:
         names = ["node", "sphere", "rect", "box", "medium", "misc", "ctx", "done", "node_fast"]
         return {n: (r[i], l[i], (l[i] / (64.0 * r[i])) if r[i] else 0.0) for i, n in enumerate(names)}
 
-    def render(self, cam, params, row_ids, want_stats=False):
-        """rt_render with host buffers → (n_rows, width, 3) float64 sums [, rt_stats]."""
+    def render(self, cam, params, row_ids, want_stats=False, progress=None):
+        """rt_render with host buffers → (n_rows, width, 3) float64 sums [, rt_stats].
+        progress: a callable (worker, paths_done, paths_total), rt_params.progress_cb."""
         rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
         p = F.rt_params.from_buffer_copy(params)
         p.n_rows = len(rows)
         p.row_ids = rows.ctypes.data
         if want_stats:
             p.flags |= F.RT_FLAG_COUNTERS
+        if progress is not None:
+            cb = F.PROGRESS_CB(lambda user, worker, done, total: progress(worker, done, total))      # (kept alive until the call returns)
+            p.progress_cb = C.cast(cb, C.c_void_p).value
         out = np.empty((len(rows), p.width, 3), dtype=np.float64)
         st = F.rt_stats()
         F.check(F.lib().rt_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
@@ -87,13 +91,16 @@ class DeviceSceneSet:
         self._h = C.c_void_p()
         F.check(F.lib().rt_scene_set_create(C.byref(desc), device_mask, C.byref(self._h)))
 
-    def render(self, cam, params, row_ids, want_stats=False):
+    def render(self, cam, params, row_ids, want_stats=False, progress=None):
         rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
         p = F.rt_params.from_buffer_copy(params)
         p.n_rows = len(rows)
         p.row_ids = rows.ctypes.data
         if want_stats:
             p.flags |= F.RT_FLAG_COUNTERS
+        if progress is not None:                     # (called from the devices' host threads, concurrently: ctypes takes the GIL for each call)
+            cb = F.PROGRESS_CB(lambda user, worker, done, total: progress(worker, done, total))
+            p.progress_cb = C.cast(cb, C.c_void_p).value
         out = np.empty((len(rows), p.width, 3), dtype=np.float64)
         st = F.rt_stats()
         F.check(F.lib().rt_render_multi(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))

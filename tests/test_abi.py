@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(rt):
 def test_abi_version_and_struct_layout(rt):
     from raytracer_2022_amd import _ffi as F
     lib = rt.lib()
-    assert lib.rt_abi_version() == F.RT2022_ABI_VERSION == 2
+    assert lib.rt_abi_version() == F.RT2022_ABI_VERSION == 3
     out = (C.c_uint32 * 64)()
     n = lib.rtb_abi_sizes(out, 64)
     assert n == len(F.ABI_STRUCTS)
