@@ -384,6 +384,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra steps without RT_FLAG_KERNEL_TIMES")
+    ap.add_argument("--frames-per-call", type=int, default=0,
+                    help="steps (frames per GPU) handed to the library per rt_render_device call; default: min(4, steps, what keeps the call's partial sums under 100 GB)")
     ap.add_argument("--pmc-seconds", type=float, default=240.0, help="time budget of the counter passes")
     ap.add_argument("--assets", default=os.path.join(HERE, "assets"))
     ap.add_argument("--inner-frame", action="store_true", help=argparse.SUPPRESS)
@@ -410,11 +412,22 @@ def main():
     scene_name, W, H, spp, desc_text = CONFIGS[args.config]
     if args.spp > 0:
         spp = args.spp
-    n_frames = world if args.scaling == "weak" else 1
-    rows_per_gpu = H * n_frames // world
+    # One STEP = one frame per GPU (weak scaling; strong: one frame over all GPUs). Steps are handed to the library a few frames at a
+    # time — ONE rt_render_device call renders `fpc` frames' worth of rows, an fpc-frame film strip whose frames differ only in their
+    # RNG key (rt2022.h: row id g = frame g / height) — because the engine drains its path pool at the end of every call: the last
+    # third of a frame's passes run on a thinning pool (tools/passlog.py: 7.5 % of the traversal time of a one-frame call is that
+    # tail), and inside one call the next frame's paths fill the slots the previous frame's stragglers leave free.
+    # Every frame of a strip is bit-identical to the same frame rendered alone (tests/test_gpu_parity.py). Limits: the per-sample
+    # partial sums of a call (24 B x spp x pixels x fpc) stay under 100 GB, and fpc <= 4.
+    frames_per_step = world if args.scaling == "weak" else 1                 # over all GPUs
+    rows_per_gpu_step = H * frames_per_step // world
+    per_sample = rows_per_gpu_step * W * 24.0                                # bytes of partial sums per sample index and step on one GPU
+    if args.frames_per_call > 0:
+        fpc = args.frames_per_call
+    else:
+        fpc = int(max(1, min(4, max(args.steps, 1), 100e9 // max(spp * per_sample, 1.0))))
     if args.spp_chunk < 0:
-        per_sample = rows_per_gpu * W * 24.0                # bytes of partial sums per sample index on one GPU
-        args.spp_chunk = max(1, int(-(-spp * per_sample // 100e9)))
+        args.spp_chunk = max(1, int(-(-spp * per_sample * fpc // 100e9)))
 
     # Counter passes first: child processes, started before this process has touched the GPU.
     pmc, pmc_note = (None, "N > 1" if world > 1 else "--no-pmc")
@@ -447,19 +460,7 @@ def main():
     assets = args.assets if os.path.isdir(args.assets) else None
     scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
     cam, bg = scene.default_view(W / H)
-    params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=n_frames, spp_chunk=args.spp_chunk)
-    params.flags |= F.RT_FLAG_KERNEL_TIMES
     dscene = rt.DeviceScene(scene.desc)
-
-    rows = film.rank_rows(H, n_frames, args.seed, rank, world)
-    n_rows = len(rows)
-    d_rows = torch.from_numpy(rows.view(np.int32)).to(dev)
-    d_out = torch.empty((n_rows, W, 3), dtype=torch.float64, device=dev)
-    # (strong scaling deals H rows over `world` ranks: the shares differ by at most one row; gather needs equal shapes)
-    max_rows = -(-H * n_frames // world)
-    d_pad = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev) if max_rows != n_rows else None
-    gather_list = [torch.empty((max_rows, W, 3), dtype=torch.float64, device="cpu" if rehearsal else dev) for _ in range(world)] \
-        if (world > 1 and rank == 0 and not args.no_gather) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -467,67 +468,109 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(stats=None, prm=None):
-        dscene.render_device(cam, prm if prm is not None else params, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, stats)
-        if world > 1 and not args.no_gather:
-            src = d_out
-            if d_pad is not None:
-                d_pad[:n_rows].copy_(d_out)
-                src = d_pad
-            dist.gather(coll(src), gather_list, dst=0)
+    class Call:
+        """One rt_render_device call over `k` steps' worth of rows: its row list, buffers, parameters and (counter pass) its ray counts."""
+        def __init__(self, k):
+            self.k = k
+            self.n_frames = frames_per_step * k
+            self.params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, n_frames=self.n_frames, spp_chunk=args.spp_chunk)
+            self.params.flags |= F.RT_FLAG_KERNEL_TIMES
+            self.plain = F.rt_params.from_buffer_copy(self.params)
+            self.plain.flags &= ~F.RT_FLAG_KERNEL_TIMES
+            rows = film.rank_rows(H, self.n_frames, args.seed, rank, world)
+            self.n_rows = len(rows)
+            self.d_rows = torch.from_numpy(rows.view(np.int32)).to(dev)
+            self.d_out = torch.empty((self.n_rows, W, 3), dtype=torch.float64, device=dev)
+            # (strong scaling deals the rows over `world` ranks: the shares differ by at most one row; gather needs equal shapes)
+            max_rows = -(-H * self.n_frames // world)
+            self.d_pad = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev) if max_rows != self.n_rows else None
+            self.gather_list = [torch.empty((max_rows, W, 3), dtype=torch.float64, device="cpu" if rehearsal else dev) for _ in range(world)] \
+                if (world > 1 and rank == 0 and not args.no_gather) else None
+            # counter pass (untimed, deterministic): rays / node visits / primitive tests of this call
+            pc = F.rt_params.from_buffer_copy(self.params)
+            pc.flags = F.RT_FLAG_COUNTERS
+            st = F.rt_stats()
+            dscene.render_device(cam, pc, self.d_rows.data_ptr(), self.n_rows, self.d_out.data_ptr(), stream, st)
+            dscene.wait(stream)
+            self.counts = st.as_dict()
 
-    # Counter pass (untimed, deterministic): rays / node visits / primitive tests of one step.
-    pc = F.rt_params.from_buffer_copy(params)
-    pc.flags = F.RT_FLAG_COUNTERS
-    st = F.rt_stats()
-    dscene.render_device(cam, pc, d_rows.data_ptr(), n_rows, d_out.data_ptr(), stream, st)
-    dscene.wait(stream)
-    counts = st.as_dict()
+        def run(self, stats=None, plain=False):
+            dscene.render_device(cam, self.plain if plain else self.params, self.d_rows.data_ptr(), self.n_rows, self.d_out.data_ptr(), stream, stats)
+            if world > 1 and not args.no_gather:
+                src = self.d_out
+                if self.d_pad is not None:
+                    self.d_pad[:self.n_rows].copy_(self.d_out)
+                    src = self.d_pad
+                dist.gather(coll(src), self.gather_list, dst=0)
 
-    for _ in range(args.warmup):
-        step()
+    def split(n_steps):          # n_steps as calls of fpc steps (+ one shorter call for the remainder)
+        return [fpc] * (n_steps // fpc) + ([n_steps % fpc] if n_steps % fpc else [])
+    calls = {}
+    for k in sorted(set(split(args.steps) + split(args.warmup) + [min(fpc, max(args.steps, 1))]), reverse=True):
+        calls[k] = Call(k)
+    main_call = calls[min(fpc, max(args.steps, 1))]
+
+    for k in split(args.warmup):
+        calls[k].run()
     barrier()
-    kernel_ms, trace_ms, shade_ms, passes = [], [], [], []
+    kernel_ms, trace_ms, shade_ms, passes = 0.0, 0.0, 0.0, 0
+    timed_counts = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in split(args.steps):
         s = F.rt_stats()
-        step(s)
+        calls[k].run(s)
         dscene.wait(stream)          # fills s.ms / s.trace_ms / s.shade_ms from the HIP events on `stream`
-        kernel_ms.append(s.ms); trace_ms.append(s.trace_ms); shade_ms.append(s.shade_ms); passes.append(s.passes)
+        kernel_ms += s.ms; trace_ms += s.trace_ms; shade_ms += s.shade_ms; passes += s.passes
     barrier()
     elapsed = time.perf_counter() - t0
+    # what the timed region did, from the counter passes of its calls
+    counts = None
+    for k in split(args.steps):
+        c = calls[k].counts
+        if counts is None:
+            counts = {key: (list(v) if isinstance(v, (list, tuple)) else v) for key, v in c.items()}
+        else:
+            for key, v in c.items():
+                if isinstance(v, (list, tuple)):
+                    counts[key] = [x + y for x, y in zip(counts[key], v)]
+                elif isinstance(v, (int, float)):
+                    counts[key] = counts[key] + v
+    if counts is None:
+        counts = dict(main_call.counts)
+    n_steps_counted = max(args.steps, 1) if args.steps else main_call.k
 
     # The plain path beside it (ADVICE r2): the timed steps above carry RT_FLAG_KERNEL_TIMES — two HIP events around every pass,
-    # which the roofline needs — so a few more steps run without the flag, the way a caller would, and the line reports both.
-    n_plain = 0 if args.no_plain else min(args.steps, 3)
+    # which the roofline needs — so one more call runs without the flag, the way a caller would, and the line reports both.
+    n_plain = 0 if (args.no_plain or not args.steps) else main_call.k
     elapsed_plain = 0.0
     if n_plain:
-        plain = F.rt_params.from_buffer_copy(params)
-        plain.flags &= ~F.RT_FLAG_KERNEL_TIMES
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n_plain):
-            step(None, plain)
-            dscene.wait(stream)
+        main_call.run(None, plain=True)
+        dscene.wait(stream)
         barrier()
         elapsed_plain = time.perf_counter() - t0
 
     t = torch.tensor([elapsed, elapsed_plain], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([counts["rays"], counts["paths"]], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([counts["rays"], counts["paths"], main_call.counts["rays"]], dtype=torch.float64, device=dev)
     if world > 1:
         t, cnt = coll(t), coll(cnt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     elapsed, elapsed_plain = float(t[0].item()), float(t[1].item())
-    total_rays, total_paths = float(cnt[0].item()), float(cnt[1].item())
+    total_rays, total_paths, plain_rays = float(cnt[0].item()), float(cnt[1].item()), float(cnt[2].item())     # of the whole timed region, all ranks
 
     if rank == 0:
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
-        value = total_rays * args.steps / elapsed / 1e6 if args.steps else 0.0
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        tr_ms = float(np.mean(trace_ms)) if trace_ms else float("nan")
-        sh_ms = float(np.mean(shade_ms)) if shade_ms else float("nan")
-        n_pass = int(round(float(np.mean(passes)))) if passes else 0
+        value = total_rays / elapsed / 1e6 if args.steps else 0.0
+        # per STEP figures of rank 0 (the roofline is about one GPU's kernels): totals of the timed region / steps
+        for key, v in list(counts.items()):
+            counts[key] = [x / n_steps_counted for x in v] if isinstance(v, list) else (v / n_steps_counted if isinstance(v, (int, float)) else v)
+        k_ms = kernel_ms / n_steps_counted if args.steps else float("nan")
+        tr_ms = trace_ms / n_steps_counted if args.steps else float("nan")
+        sh_ms = shade_ms / n_steps_counted if args.steps else float("nan")
+        n_pass = passes / n_steps_counted if args.steps else 0          # pass pairs per step (a call of fpc steps shares its passes among them)
+        n_rows = main_call.n_rows // main_call.k
         ab = algorithmic_bytes(counts, n_rows * W)
         gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
         rnd = lambda x, n=2: None if x is None else round(x, n)
@@ -673,17 +716,22 @@ def main():
             "synthetic — REHEARSAL over %s with ranks sharing GPUs: not a measurement" % backend,
             "config": {"workload": desc_text if args.spp == 0 else desc_text + " [spp overridden to %d]" % spp,
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "max_depth": 50,
-                       "frames": n_frames, "rows_per_gpu": n_rows, "spp_chunk": int(s.spp_chunk) if kernel_ms else args.spp_chunk,
-                       "pool_slots": int(s.pool_slots) if kernel_ms else None, "seed": args.seed,
+                       "frames": frames_per_step, "rows_per_gpu": n_rows, "spp_chunk": int(s.spp_chunk) if args.steps else args.spp_chunk,
+                       "pool_slots": int(s.pool_slots) if args.steps else None, "seed": args.seed,
+                       "steps_per_call": fpc, "calls": split(args.steps),
+                       "steps_per_call_note": "a step is one frame per GPU; the library gets them %d at a time (one rt_render_device call = a %d-frame strip, frames keyed "
+                                              "0..%d): its path pool drains once per call instead of once per frame; every frame's pixels are those of the frame rendered alone"
+                                              % (fpc, fpc * frames_per_step, fpc * frames_per_step - 1),
+                       "call_latency_ms": round(elapsed / max(len(split(args.steps)), 1) * 1e3, 3) if args.steps else None,
                        "sharding": ("rows of an N-frame strip dealt cyclically (one frame's worth per GPU)" if args.scaling == "weak"
                                     else "rows of ONE frame dealt cyclically over the GPUs") + "; gather of row buffers to rank 0",
                        "assets": ("assets/ (the reference's earthmap / planet JPEGs and Shuttle.obj)" if assets and os.path.exists(os.path.join(assets, "earthmap.jpg"))
                                   else "procedural stand-ins (no assets directory)"),
                        "triangles": int(scene.desc.n_triangles), "bvh_nodes": int(scene.desc.n_nodes)},
-            "rays_per_step": int(total_rays), "paths_per_step": int(total_paths),
-            "plain_path": ({"value": round(total_rays * n_plain / elapsed_plain / 1e6, 2), "unit": "Mrays/s", "steps": n_plain,
+            "rays_per_step": int(round(total_rays / max(args.steps, 1))), "paths_per_step": int(round(total_paths / max(args.steps, 1))),
+            "plain_path": ({"value": round(plain_rays / elapsed_plain / 1e6, 2), "unit": "Mrays/s", "steps": n_plain,
                             "ms_per_step": round(elapsed_plain / n_plain * 1e3, 3),
-                            "note": "the same steps without RT_FLAG_KERNEL_TIMES (no HIP events around the passes), run after the timed region; `value` above is the timed region's"}
+                            "note": "one more call of the same size without RT_FLAG_KERNEL_TIMES (no HIP events around the passes), run after the timed region; `value` above is the timed region's"}
                            if n_plain and elapsed_plain > 0 else None),
             "roofline": roof,
             "counters_rank0": counts,

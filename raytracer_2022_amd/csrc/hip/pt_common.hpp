@@ -40,13 +40,13 @@ constexpr uint32_t REF_MED2 = 13u << RT_REF_KIND_SHIFT;       // medium: second 
 constexpr uint32_t REF_EMPTY = 14u << RT_REF_KIND_SHIFT;      // stack exhausted
 constexpr uint32_t REF_POPCTX = 15u << RT_REF_KIND_SHIFT;     // leave the innermost mover
 
-RT_DEV uint32_t classify(uint32_t ref) {
-    // kind -> op, 4 bits per kind (NODE..LIST, 12/13 unused, EMPTY, POPCTX)
-    const unsigned long long table = ((unsigned long long)OP_MEDIUM << 48) | ((unsigned long long)OP_MEDIUM << 52) |
+// kind -> op, 4 bits per kind (NODE..LIST, 12/13 unused, EMPTY, POPCTX)
+constexpr unsigned long long kClassifyTable = ((unsigned long long)OP_MEDIUM << 48) | ((unsigned long long)OP_MEDIUM << 52) |
                                      ((unsigned long long)OP_SHADE << 56) | ((unsigned long long)OP_CTX << 60) | (unsigned long long)OP_NODE | ((unsigned long long)OP_SPHERE << 4) | ((unsigned long long)OP_SPHERE << 8) |
                                      ((unsigned long long)OP_RECT << 12) | ((unsigned long long)OP_BOX << 16) | ((unsigned long long)OP_MISC << 20) |
                                      ((unsigned long long)OP_MISC << 24) | ((unsigned long long)OP_MEDIUM << 28) | ((unsigned long long)OP_CTX << 32) |
                                      ((unsigned long long)OP_CTX << 36) | ((unsigned long long)OP_CTX << 40) | ((unsigned long long)OP_CTX << 44);
+RT_DEV uint32_t classify(uint32_t ref, unsigned long long table = kClassifyTable) {
     return (uint32_t)(table >> (RT_REF_KIND(ref) * 4)) & 0xFu;
 }
 
@@ -175,15 +175,16 @@ RT_DEV void xform_record(const SceneDev &s, uint32_t ref, const XRay &moved, Hit
 }
 
 // Chain of enclosing movers, outermost first.
+// (1, r3: the four refs picked with shifts of two 64-bit words. The select form below — 0 — is what the compiler turns into a
+// dynamically indexed private array: 32-48 bytes of scratch per lane in every traversal kernel with movers)
 #ifndef RT2022_CHAIN_PACKED
-#define RT2022_CHAIN_PACKED 0
+#define RT2022_CHAIN_PACKED 1
 #endif
 struct Chain {
     uint32_t c0, c1, c2, c3;
     uint32_t n;
 #if RT2022_CHAIN_PACKED
-    // (A/B form for tools/mega_bisect.sh: the four refs picked with shifts of two 64-bit words, which the
-    // compiler cannot turn into an indexed private array.)
+    // (the four refs picked with shifts of two 64-bit words, which the compiler cannot turn into an indexed private array)
     RT_DEV uint32_t at(uint32_t i) const {
         const uint64_t lo = (uint64_t)c0 | ((uint64_t)c1 << 32), hi = (uint64_t)c2 | ((uint64_t)c3 << 32);
         return (uint32_t)(((i & 2u) ? hi : lo) >> ((i & 1u) * 32u));

@@ -62,6 +62,7 @@ constexpr uint32_t kChunk = RT2022_CHUNK;           // list entries a wave claim
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // (records whose size is 8 mod 16)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <class T>
 RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
 // The wave's vote as the hardware gives it (a v_cmp into an SGPR pair); HIP's __ballot materialises the predicate as 0 / 1 first.
@@ -925,7 +926,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     __shared__ double wray_lds[kStash ? 6 * WG : 6];
     // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node.
     __shared__ f64x2 nc_box[CACHE > 0 ? 3 * CACHE : 1];
-    __shared__ uint2 nc_ref[CACHE > 0 ? CACHE : 1];
+    __shared__ u32x2 nc_ref[CACHE > 0 ? CACHE : 1];
     // ... and, in every variant (384 bytes), the first records of the two small tables the arms go to most: movers (32 B
     // each) and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
 #ifndef RT2022_SMALL_TABLES_EVERYWHERE
@@ -950,7 +951,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         for (uint32_t i = tid; i < n_cached; i += (uint32_t)WG) {
             const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + i);
             f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
-            const uint2 rr = reinterpret_cast<const uint2 *>(np)[6];
+            const u32x2 rr = reinterpret_cast<const u32x2 *>(np)[6];
             nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
             nc_ref[i] = rr;
         }
@@ -1033,6 +1034,18 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     constexpr int tail_factor = 2;
     const bool boxes_plain = (node_quorum_u >> 31) != 0;             // host: every node box finite with min <= max
     unsigned census_rounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, census_lanes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // What the node fast path keeps in registers across its turns (r3). The library is built without MachineLICM (Makefile:
+    // hoisted f64 literals were being spilled), so nothing hoists a loop's constants any more — and in THIS loop every
+    // instruction counts: rebuilding the classify table, the empty-stack ref and the two LDS table addresses each turn is five
+    // more instructions per node step (C2: -5 %). The empty asm makes each an opaque value: it cannot be rebuilt inside.
+    unsigned long long ctab = kClassifyTable;
+    uint32_t ref_empty = REF_EMPTY;
+    asm volatile("" : "+s"(ctab), "+v"(ref_empty));                  // (a select takes one scalar operand, and that is its lane mask)
+    typedef const __attribute__((address_space(3))) f64x2 *LdsBoxPtr;
+    typedef const __attribute__((address_space(3))) u32x2 *LdsRefPtr;
+    LdsBoxPtr ncb = (LdsBoxPtr)nc_box;
+    LdsRefPtr ncr = (LdsRefPtr)nc_ref;
+    if (CACHE > 0) asm volatile("" : "+v"(ncb), "+v"(ncr));
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to — nn >= the quorum. Below the quorum the vote
@@ -1049,6 +1062,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const int pending = __popcll(wballot(L.op != OP_IDLE));
             const int tail_threshold = tail_factor * pending / (tail_factor + 1) + 1;
             const int threshold = node_quorum < tail_threshold ? node_quorum : tail_threshold;
+            // (t_lo and t_hi do not change inside the loop: a lane can only leave it)
+            double tlo_c = L.t_lo, thi_c = t_hi(L);
+            asm volatile("" : "+v"(tlo_c), "+v"(thi_c));              // (in vector registers, once per entry)
             if (isn && nn >= threshold) do {
                 if (STATS) { const unsigned long long am = wballot(true); if ((int)lane == __ffsll((long long)am) - 1) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; } }
                 {
@@ -1070,10 +1086,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
-                    f64x2 c0 = nc_box[3 * nidx], c1 = nc_box[3 * nidx + 1], c2 = nc_box[3 * nidx + 2];
-                    uint2 cr = nc_ref[nidx];
+                    f64x2 c0 = ncb[3 * nidx], c1 = ncb[3 * nidx + 1], c2 = ncb[3 * nidx + 2];
+                    u32x2 cr = ncr[nidx];
                     below = st.col[below_sp * WG];
-                    t_pin(c0); t_pin(c1); t_pin(c2); t_pin(cr.x); t_pin(cr.y); t_pin(below);      // (all five reads issued before the arithmetic: one wait)
+                    t_pin(c0); t_pin(c1); t_pin(c2); t_pin(cr); t_pin(below);      // (all five reads issued before the arithmetic: one wait)
                     bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
                     left = cr.x; right = cr.y;
                 } else {
@@ -1084,13 +1100,17 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     bmax[0] = rtm::u2d(((uint64_t)q1.w << 32) | q1.z); bmax[1] = rtm::u2d(((uint64_t)q2.y << 32) | q2.x); bmax[2] = rtm::u2d(((uint64_t)q2.w << 32) | q2.z);
                     left = q3.x; right = q3.y;
                 }
-                double tmn = L.t_lo, tmx = t_hi(L);
+                double tmn, tmx;
 #pragma unroll
                 for (int i = 0; i < 3; i++) {
                     double t0 = (bmin[i] - L.cur.o[i]) * L.inv[i];
                     double t1 = (bmax[i] - L.cur.o[i]) * L.inv[i];
-                    tmn = __builtin_fmax(tmn, __builtin_fmin(t0, t1));
-                    tmx = __builtin_fmin(tmx, __builtin_fmax(t0, t1));
+                    const double lo = __builtin_fmin(t0, t1), hi = __builtin_fmax(t0, t1);
+                    // fmax / fmin of a value that is not an arithmetic result of the same block first "canonicalises" it (a
+                    // v_max_f64 x, x) — per node step, for the window's two ends, which never change in here. Written as the
+                    // instruction fmax / fmin compile to; no operand is a NaN on this path (see above), so it is the same value.
+                    asm("v_max_f64 %0, %1, %2" : "=v"(tmn) : "v"(i == 0 ? tlo_c : tmn), "v"(lo));
+                    asm("v_min_f64 %0, %1, %2" : "=v"(tmx) : "v"(i == 0 ? thi_c : tmx), "v"(hi));
                 }
                 const bool hit = !(tmx <= tmn);
                 // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
@@ -1102,10 +1122,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 const bool push = hit && !twin && L.sp < STACK;
                 if (push) st.col[L.sp * WG] = right;
                 if (STATS && hit && twin) cnt.prim(lk);
-                const uint32_t next = hit ? left : (L.sp > 0 ? below : REF_EMPTY);
+                const uint32_t next = hit ? left : (L.sp > 0 ? below : ref_empty);
                 L.sp = hit ? L.sp + (push ? 1 : 0) : below_sp;
                 L.top = next;
-                L.op = classify(next);                            // (media met here start in their own arm)
+                L.op = classify(next, ctab);                      // (media met here start in their own arm)
                 }
                 isn = L.op == OP_NODE;
                 nn = __popcll(wballot(isn));
@@ -1141,7 +1161,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             u32x4 n3;
             if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
-                const uint2 cr = nc_ref[nidx];
+                const u32x2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, cr.y, 0u, 0u};
             } else {
                 const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + nidx);

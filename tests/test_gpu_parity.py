@@ -591,3 +591,50 @@ def test_full_size_properties_of_the_other_configs(rt, O, scene, W, H, param, as
     out, st = dev.render(cam, p, rows[:4], want_stats=True)
     assert st.as_dict() == st_ref.as_dict()
     assert np.array_equal(bits(out), bits(ref)) and np.array_equal(bits(full[:4]), bits(ref))
+
+
+def test_c1_at_its_stated_size(rt, O):
+    """BASELINE config 1 — book-1 final scene, 400x225, 100 spp, depth 50, 'CPU reference path only' — at its own size:
+    the oracle renders a sample of full-width rows at the full 100 spp (the whole frame is bench.py --config c1's CPU leg)
+    and the HIP path gives the same bits and counters; the whole frame on the HIP path is deterministic and its rows do not
+    depend on what else is in the call."""
+    W, H, spp = 400, 225, 100
+    s = rt.HostScene("random_scene", seed=2022)
+    cam, bg = s.default_view(W / H)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
+    rows = rt.shuffled_rows(H, 2022)
+    full, st_full = dev.render(cam, p, rows, want_stats=True)
+    assert st_full.paths == W * H * spp
+    ref, st_ref = O.render_cpu(s.desc, cam, p, rows[:10], n_threads=8, want_stats=True)
+    out, st = dev.render(cam, p, rows[:10], want_stats=True)
+    assert st.as_dict() == st_ref.as_dict()
+    assert np.array_equal(bits(out), bits(ref)) and np.array_equal(bits(full[:10]), bits(ref))
+    assert np.array_equal(rt.write_color(full[:10], spp), O.write_color(ref, spp))
+    p0 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=0)        # the reference's own loop order, one item per pixel
+    assert np.array_equal(bits(dev.render(cam, p0, rows[100:110])), bits(full[100:110]))
+
+
+def test_frames_of_a_strip_are_the_frames_rendered_alone(rt, O):
+    """bench.py hands the library several frames per call (an n_frames strip: row id g = frame g / height, frames differ in
+    their RNG key only) so that the pool drains once per call. Every frame of the strip must be the frame rendered by itself,
+    bit for bit, and a strip frame must equal the oracle's."""
+    W, H, spp, nf = 96, 64, 6, 3
+    s = rt.HostScene("final_scene", seed=2022)
+    cam, bg = s.default_view(W / H)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022, n_frames=nf, spp_chunk=1)
+    from raytracer_2022_amd import film
+    strip_rows = film.strip_rows(H, nf, 2022)                         # all rows of all frames, shuffled together
+    strip = dev.render(cam, p, strip_rows)
+    for f in range(nf):
+        mine = np.flatnonzero(strip_rows // H == f)
+        alone = dev.render(cam, p, strip_rows[mine])                  # the same rows in a call of their own
+        assert np.array_equal(bits(alone), bits(strip[mine]))
+    f1 = np.flatnonzero(strip_rows // H == 1)[:8]
+    ref = O.render_cpu(s.desc, cam, p, strip_rows[f1], n_threads=4)
+    assert np.array_equal(bits(strip[f1]), bits(ref))
+    # and frame 0 of a strip is the single-frame render (n_frames = 1) of the same seed
+    p1 = rt.make_params(W, H, spp, 50, bg, seed=2022, n_frames=1, spp_chunk=1)
+    f0 = np.flatnonzero(strip_rows // H == 0)
+    assert np.array_equal(bits(dev.render(cam, p1, strip_rows[f0])), bits(strip[f0]))

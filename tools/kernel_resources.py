@@ -16,7 +16,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(HERE, "raytracer_2022_amd", "csrc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "--offload-arch=gfx950", "-fno-slp-vectorize",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm",
          "-Rpass-analysis=kernel-resource-usage"]
 FIELDS = [("VGPRs", "VGPRs"), ("TotalSGPRs", "SGPRs"), ("SGPRs Spill", "sgpr_spill"), ("VGPRs Spill", "vgpr_spill"),
           ("ScratchSize [bytes/lane]", "scratch"), ("LDS Size [bytes/block]", "lds"), ("Occupancy [waves/SIMD]", "waves")]
