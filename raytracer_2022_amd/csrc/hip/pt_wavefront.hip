@@ -179,17 +179,26 @@ RT_DEV uint32_t leaf_material_word(const SceneDev &s, uint32_t leaf) {
 // the kind (the longest records — Triangle, MovingSphere — are 80 bytes; shorter ones run on into their neighbour or
 // into the pool's zeroed slack, rt_scene_create) — one address computation, five loads, no branch.
 struct PrimRegs { f64x2 r0, r1, r2, r3, r4; };
-RT_DEV const f64x2_a8 *prim_address(const SceneDev &s, uint32_t leaf) {
+// ... with the pools' base addresses and record sizes taken from a 16-entry table in LDS, indexed by kind (wf_shade fills it
+// once): seven pointer pairs need not sit in scalar registers through the whole shade loop (r3: they were being spilled), and
+// the select chain below becomes one 8-byte LDS read.
+struct PrimTable { unsigned long long base[16]; uint32_t stride[16]; };
+RT_DEV void prim_table_fill(const SceneDev &s, PrimTable &t, uint32_t tid) {
+    if (tid < 16) {
+        const void *b = s.media; uint32_t st = (uint32_t)sizeof(rt_medium);
+        if (tid == RT_KIND_SPHERE) { b = s.spheres; st = (uint32_t)sizeof(rt_sphere); }
+        else if (tid == RT_KIND_MOVING_SPHERE) { b = s.moving_spheres; st = (uint32_t)sizeof(rt_moving_sphere); }
+        else if (tid == RT_KIND_RECT) { b = s.rects; st = (uint32_t)sizeof(rt_rect); }
+        else if (tid == RT_KIND_BOX) { b = s.boxes; st = (uint32_t)sizeof(rt_box); }
+        else if (tid == RT_KIND_TRIANGLE) { b = s.triangles; st = (uint32_t)sizeof(rt_triangle); }
+        else if (tid == RT_KIND_RING) { b = s.rings; st = (uint32_t)sizeof(rt_ring); }
+        t.base[tid] = (unsigned long long)reinterpret_cast<uintptr_t>(b);
+        t.stride[tid] = st;
+    }
+}
+RT_DEV const f64x2_a8 *prim_address(const PrimTable &t, uint32_t leaf) {
     const uint32_t kind = RT_REF_KIND(leaf), idx = RT_REF_INDEX(leaf);
-    const char *base = reinterpret_cast<const char *>(s.media);
-    uint32_t stride = (uint32_t)sizeof(rt_medium);
-    if (kind == RT_KIND_SPHERE) { base = reinterpret_cast<const char *>(s.spheres); stride = (uint32_t)sizeof(rt_sphere); }
-    else if (kind == RT_KIND_MOVING_SPHERE) { base = reinterpret_cast<const char *>(s.moving_spheres); stride = (uint32_t)sizeof(rt_moving_sphere); }
-    else if (kind == RT_KIND_RECT) { base = reinterpret_cast<const char *>(s.rects); stride = (uint32_t)sizeof(rt_rect); }
-    else if (kind == RT_KIND_BOX) { base = reinterpret_cast<const char *>(s.boxes); stride = (uint32_t)sizeof(rt_box); }
-    else if (kind == RT_KIND_TRIANGLE) { base = reinterpret_cast<const char *>(s.triangles); stride = (uint32_t)sizeof(rt_triangle); }
-    else if (kind == RT_KIND_RING) { base = reinterpret_cast<const char *>(s.rings); stride = (uint32_t)sizeof(rt_ring); }
-    return reinterpret_cast<const f64x2_a8 *>(base + (uint64_t)idx * stride);
+    return reinterpret_cast<const f64x2_a8 *>(static_cast<uintptr_t>(t.base[kind] + (unsigned long long)idx * t.stride[kind]));
 }
 // winner_record (pt_common.hpp) fed from registers: the HitRecord of the winning candidate, rebuilt from (leaf, t) in
 // the leaf's own frame (sphere.rs:59-65,158-164, aarect.rs:51-71, boxes.rs:24-66, triangle.rs:54-76, ring.rs:49-52,
@@ -312,6 +321,8 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     // the reference): MixturePdf's two visits per bounce (generate + value, pdf.rs:94-104) then cost no memory round trip.
     constexpr uint32_t kLdsLights = 8;
     __shared__ LightRec lights_lds[kLdsLights];
+    __shared__ PrimTable prim_tab;
+    prim_table_fill(s, prim_tab, tid);
     if (tid < kLdsLights && tid < s.n_lights) lights_lds[tid] = fetch_light(s, tid);
     auto light_at = [&](uint32_t li) { return li < kLdsLights ? lights_lds[li] : fetch_light(s, li); };
     SP_DECL;
@@ -391,7 +402,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 PoolView::decode_hit(ha, hb, w, steps, mat_word, have_mat);
                 if (!have_mat) mat_word = leaf_material_word(s, w.leaf);      // (four movers deep: the chain needed the word's place)
                 // second round trip, everything at once: the winning primitive's record and its material's
-                const f64x2_a8 *pp = prim_address(s, w.leaf);
+                const f64x2_a8 *pp = prim_address(prim_tab, w.leaf);
                 const f64x2 *mp = reinterpret_cast<const f64x2 *>(s.materials_dev + (mat_word & kMatIndexMask));
                 prim.r0 = pp[0]; prim.r1 = pp[1]; prim.r2 = pp[2]; prim.r3 = pp[3]; prim.r4 = pp[4];
                 md0 = mp[0]; md1 = mp[1]; md2 = mp[2]; md3 = mp[3]; md4 = mp[4];
@@ -892,8 +903,11 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK, WG> &st, double 
 
 // Resident traversal workgroups per CU a variant is built and launched for (= waves per SIMD = its VGPR budget):
 // the sphere-only kernel needs 82 VGPRs and runs five (C2: +4 % over four; six would spill), the full kernels four.
+#ifndef RT2022_LEAN_BLOCKS
+#define RT2022_LEAN_BLOCKS 5           // resident workgroups per CU of the sphere-only kernels (FEAT = 0, 256 threads)
+#endif
 constexpr int trace_blocks_per_cu(int stack, bool stats, unsigned feat) {
-    return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? 5 : kTraceBlocksPerCU;
+    return stack > 32 ? 2 : stats ? 3 : (stack > kStackSmall || (feat & kFeatMisc)) ? 4 : feat == 0 ? RT2022_LEAN_BLOCKS : kTraceBlocksPerCU;
 }
 // The node-cache variant (WG = kCacheBlock threads, one workgroup per CU, CACHE = kNodeCache records): the BVH's first
 // CACHE node records live in LDS — 48 bytes of box and 8 of child refs each — beside the traversal stacks of the
@@ -951,7 +965,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         for (uint32_t i = tid; i < n_cached; i += (uint32_t)WG) {
             const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + i);
             f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
-            const u32x2 rr = reinterpret_cast<const u32x2 *>(np)[6];
+            const u32x4 rw = reinterpret_cast<const u32x4 *>(np)[3];          // {left, right, push ref, -}: see rt_scene_create
+            const u32x2 rr = {rw.x, rw.z};
             nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
             nc_ref[i] = rr;
         }
@@ -1065,7 +1080,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             // (t_lo and t_hi do not change inside the loop: a lane can only leave it)
             double tlo_c = L.t_lo, thi_c = t_hi(L);
             asm volatile("" : "+v"(tlo_c), "+v"(thi_c));              // (in vector registers, once per entry)
-            if (isn && nn >= threshold) do {
+            const bool entered = isn && nn >= threshold;
+            if (entered) do {
                 if (STATS) { const unsigned long long am = wballot(true); if ((int)lane == __ffsll((long long)am) - 1) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; } }
                 {
                 // BvhNode::hit, bvh/mod.rs:86-101 + AABB::hit, aabb.rs:15-32. The left child is taken
@@ -1086,10 +1102,17 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
-                    f64x2 c0 = ncb[3 * nidx], c1 = ncb[3 * nidx + 1], c2 = ncb[3 * nidx + 2];
-                    u32x2 cr = ncr[nidx];
-                    below = st.col[below_sp * WG];
-                    t_pin(c0); t_pin(c1); t_pin(c2); t_pin(cr); t_pin(below);      // (all five reads issued before the arithmetic: one wait)
+                    // (LDS addresses are 32 bits and a table index is far below 2^24: one v_mad_u32_u24 instead of a 64-bit multiply-add)
+                    const uint32_t box_at = (uint32_t)(uintptr_t)ncb + __umul24(nidx, 48u), ref_at = (uint32_t)(uintptr_t)ncr + nidx * 8u;
+                    const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
+                    // The five LDS reads of a node step, issued back to back and waited for ONCE — written out, because the compiler's
+                    // own placement of the waits split them (seen in the ISA: the child refs were waited for before the box was even
+                    // asked for: two LDS round trips per node step instead of one).
+                    f64x2 c0, c1, c2;
+                    u32x2 cr;
+                    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+                                 "ds_read_b64 %3, %6\n\tds_read_b32 %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(cr), "=&v"(below) : "v"(box_at), "v"(ref_at), "v"(below_at) : "memory");
                     bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
                     left = cr.x; right = cr.y;
                 } else {
@@ -1098,7 +1121,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     below = st.col[below_sp * WG];
                     bmin[0] = rtm::u2d(((uint64_t)q0.y << 32) | q0.x); bmin[1] = rtm::u2d(((uint64_t)q0.w << 32) | q0.z); bmin[2] = rtm::u2d(((uint64_t)q1.y << 32) | q1.x);
                     bmax[0] = rtm::u2d(((uint64_t)q1.w << 32) | q1.z); bmax[1] = rtm::u2d(((uint64_t)q2.y << 32) | q2.x); bmax[2] = rtm::u2d(((uint64_t)q2.w << 32) | q2.z);
-                    left = q3.x; right = q3.y;
+                    left = q3.x; right = q3.z;                    // (the push ref: `right`, or "nothing" for a span-1 twin — rt_scene_create)
                 }
                 double tmn, tmx;
 #pragma unroll
@@ -1116,20 +1139,23 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
                 // primitive a second time against t_max = its own t finds the same hit again, so
                 // only the count of tests is kept; anything that can draw from the RNG or carry
-                // movers (media, movers, nodes, lists) is really visited twice.
-                const uint32_t lk = RT_REF_KIND(left);
-                const bool twin = left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING;
+                // movers (media, movers, nodes, lists) is really visited twice. rt_scene_create has
+                // worked that out per node: `right` here is the node's PUSH REF — its right child, or
+                // REF_EMPTY where the twin needs no second visit (r3: one compare instead of five).
+                const bool twin = right == ref_empty;
                 const bool push = hit && !twin && L.sp < STACK;
                 if (push) st.col[L.sp * WG] = right;
-                if (STATS && hit && twin) cnt.prim(lk);
+                if (STATS && hit && twin) cnt.prim(RT_REF_KIND(left));
                 const uint32_t next = hit ? left : (L.sp > 0 ? below : ref_empty);
                 L.sp = hit ? L.sp + (push ? 1 : 0) : below_sp;
                 L.top = next;
-                L.op = classify(next, ctab);                      // (media met here start in their own arm)
+                // (a node ref is kind 0 without the FlipFace bit — rt_scene_create refuses a flipped node — so "another node step"
+                // is one compare; the label of whatever else came up is looked up once, when the lane leaves the loop)
+                isn = next < (1u << RT_REF_KIND_SHIFT);
                 }
-                isn = L.op == OP_NODE;
                 nn = __popcll(wballot(isn));
             } while (isn && nn >= threshold);
+            if (entered) L.op = classify(L.top, ctab);                // (media met in there start in their own arm)
         }
         TP_MARK(0);
         // Vote: the label most lanes are waiting on (ties -> lowest id).
@@ -1162,7 +1188,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const u32x2 cr = nc_ref[nidx];
-                n3 = (u32x4){cr.x, cr.y, 0u, 0u};
+                n3 = (u32x4){cr.x, 0u, cr.y, 0u};
             } else {
                 const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + nidx);
                 n0 = np[0]; n1 = np[1]; n2 = np[2];
@@ -1183,9 +1209,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 miss = miss || (tmx <= tmn);
             }
             if (!miss) {
-                uint32_t left = n3.x, right = n3.y, lk = RT_REF_KIND(left);
-                if (left == right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) cnt.prim(lk);
-                else st.push(L, right);
+                const uint32_t left = n3.x, push_ref = n3.z;           // (push ref: see the fast path)
+                if (push_ref == REF_EMPTY) cnt.prim(RT_REF_KIND(left));
+                else st.push(L, push_ref);
                 L.top = left;
                 L.op = classify(left);
             } else {
@@ -1222,7 +1248,18 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     mat_word = (uint32_t)rtm::d2u(q4.y);
                 }
                 double t;
-                if (sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t)) t_accept(L, t, 0, mat_word);
+                bool h = sphere_t(center, radius, L.cur, L.a_len, L.t_lo, t_hi(L), t);
+#ifdef RT2022_WHATIF_SPHERE
+                // (diagnostic build: the arm's arithmetic N times over, same result — how much of the kernel's time is this arm's
+                // arithmetic? profiles/r3d_whatif_arms.log)
+                for (int k = 1; k < RT2022_WHATIF_SPHERE; k++) {
+                    Vec3 c2 = center; double r2 = radius, t2;
+                    asm volatile("" : "+v"(c2.x), "+v"(c2.y), "+v"(c2.z), "+v"(r2));
+                    const bool h2 = sphere_t(c2, r2, L.cur, L.a_len, L.t_lo, t_hi(L), t2);
+                    h = h && h2; t = h ? t2 : t;
+                }
+#endif
+                if (h) t_accept(L, t, 0, mat_word);
                 T_NEXT();
             }
         } else if (best == OP_RECT) {
@@ -1249,7 +1286,16 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             t_pin(b0); t_pin(b1); t_pin(b2); t_pin(mat_word);
             double t;
             uint32_t face = 0;
-            if (t_box(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, L.cur, L.t_lo, t_hi(L), t, face)) t_accept(L, t, face, mat_word);
+            bool h = t_box(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, L.cur, L.t_lo, t_hi(L), t, face);
+#ifdef RT2022_WHATIF_BOX
+            for (int k = 1; k < RT2022_WHATIF_BOX; k++) {
+                f64x2 e0 = b0, e1 = b1, e2 = b2; double t2; uint32_t f2 = 0;
+                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2));
+                const bool h2 = t_box(e0.x, e0.y, e1.x, e1.y, e2.x, e2.y, L.cur, L.t_lo, t_hi(L), t2, f2);
+                h = h && h2; t = h ? t2 : t; face = h ? f2 : face;
+            }
+#endif
+            if (h) t_accept(L, t, face, mat_word);
             T_NEXT();
             }
         } else if ((FEAT & kFeatVolumes) && best == OP_MEDIUM) {      // ConstantMedium::hit, constantmedium.rs:49-83

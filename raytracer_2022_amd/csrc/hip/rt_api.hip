@@ -624,6 +624,12 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                 for (uint32_t i = 0; i < desc->n_nodes; i++) {
                     rt_bvh_node q = desc->nodes[i];
                     q.left = node_ref(q.left); q.right = node_ref(q.right);
+                    // The PUSH REF of the node, for the wavefront traversal kernels (third word of the record's last 16 bytes): what
+                    // goes on the stack when the box is hit — the right child, or "nothing" (14 << 27, their REF_EMPTY) for a span-1
+                    // node holding the same plain primitive twice (bvh/mod.rs:44-47), whose second test finds the first one's hit again
+                    // (counted, not repeated). Media, movers, lists and nodes are really visited twice: they draw from the RNG or recurse.
+                    const uint32_t lk = RT_REF_KIND(q.left);
+                    q._pad[0] = (q.left == q.right && lk >= RT_KIND_SPHERE && lk <= RT_KIND_RING) ? (14u << RT_REF_KIND_SHIFT) : q.right;
                     nodes[new_of[i]] = q;
                 }
                 s.nodes = upload(nodes.data(), nodes.size(), sc->owned);
