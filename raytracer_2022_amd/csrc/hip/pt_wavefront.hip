@@ -1103,7 +1103,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 uint32_t left, right, below;
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                     // (LDS addresses are 32 bits and a table index is far below 2^24: one v_mad_u32_u24 instead of a 64-bit multiply-add)
-                    const uint32_t box_at = (uint32_t)(uintptr_t)ncb + __umul24(nidx, 48u), ref_at = (uint32_t)(uintptr_t)ncr + nidx * 8u;
+                    // (the 24-bit multiply-add takes the low 24 bits of the ref: its index, un-masked)
+                    const uint32_t box_at = (uint32_t)(uintptr_t)ncb + __umul24(L.top, 48u), ref_at = (uint32_t)(uintptr_t)ncr + __umul24(L.top, 8u);
                     const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
                     // The five LDS reads of a node step, issued back to back and waited for ONCE — written out, because the compiler's
                     // own placement of the waits split them (seen in the ISA: the child refs were waited for before the box was even
@@ -1117,8 +1118,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     left = cr.x; right = cr.y;
                 } else {
                     const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + nidx);
-                    uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    uint4 q0 = np[0], q1 = np[1], q2 = np[2];
+                    u32x4 q3 = reinterpret_cast<const u32x4 *>(np)[3];
                     below = st.col[below_sp * WG];
+                    asm volatile("" : "+v"(q3), "+v"(below));         // (q3 as ONE 16-byte load — left and the push ref are not neighbours in it — and the stack read beside the fetches)
                     bmin[0] = rtm::u2d(((uint64_t)q0.y << 32) | q0.x); bmin[1] = rtm::u2d(((uint64_t)q0.w << 32) | q0.z); bmin[2] = rtm::u2d(((uint64_t)q1.y << 32) | q1.x);
                     bmax[0] = rtm::u2d(((uint64_t)q1.w << 32) | q1.z); bmax[1] = rtm::u2d(((uint64_t)q2.y << 32) | q2.x); bmax[2] = rtm::u2d(((uint64_t)q2.w << 32) | q2.z);
                     left = q3.x; right = q3.z;                    // (the push ref: `right`, or "nothing" for a span-1 twin — rt_scene_create)
@@ -1237,6 +1240,17 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                         mat_word = s.spheres[idx].mat;
                     }
                     t_pin(q0); t_pin(q1); t_pin(mat_word);
+#ifdef RT2022_WHATIF_SPHERE_FETCH
+                    // (diagnostic build: the record fetched a second time, behind the first — one more memory round trip per turn
+                    // of this arm, same values: how much of the kernel's time is this arm's fetch latency? profiles/r3e_whatif_arms.log)
+                    if (!PRIMS) {
+                        uint32_t z;
+                        asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"((uint32_t)rtm::d2u(q0.x)));     // 0 — once q0 has arrived
+                        const f64x2_a8 *qp2 = reinterpret_cast<const f64x2_a8 *>(s.spheres + (idx + z));
+                        q0 = qp2[0]; q1 = qp2[1];
+                        t_pin(q0); t_pin(q1);
+                    }
+#endif
                     center = Vec3(q0.x, q0.y, q1.x); radius = q1.y;
                 } else {                                              // rt_moving_sphere, 80 B: center0, center1, time0, time1, radius, mat
                     const f64x2 *qp = PRIMS ? ms_lds + 5 * idx : reinterpret_cast<const f64x2 *>(s.moving_spheres + idx);
@@ -1284,6 +1298,15 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             f64x2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
             uint32_t mat_word = s.boxes[bidx].mat;
             t_pin(b0); t_pin(b1); t_pin(b2); t_pin(mat_word);
+#ifdef RT2022_WHATIF_BOX_FETCH
+            {
+                uint32_t z;
+                asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"((uint32_t)rtm::d2u(b0.x)));
+                const f64x2_a8 *bp2 = reinterpret_cast<const f64x2_a8 *>(s.boxes + (bidx + z));
+                b0 = bp2[0]; b1 = bp2[1]; b2 = bp2[2];
+                t_pin(b0); t_pin(b1); t_pin(b2);
+            }
+#endif
             double t;
             uint32_t face = 0;
             bool h = t_box(b0.x, b0.y, b1.x, b1.y, b2.x, b2.y, L.cur, L.t_lo, t_hi(L), t, face);
