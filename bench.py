@@ -686,7 +686,12 @@ def main():
             else:
                 src = roof["hbm_counter"] if top == "hbm" else roof[top]
                 roof.update(bound=top, achieved=src["achieved"], peak=src["peak"], unit=src["unit"], frac=src["frac"])
-            roof["limiter"] = {"resource": top, "frac": limiter[0][1], "ranked": limiter,
+            waits = roof["valu"].get("wait_any_over_wave_cycles") or 0.0
+            regime = ("issue-bound: the vector pipes issue in %.0f %% of their slots" % (100 * roof["valu"]["busy"]) if roof["valu"]["busy"] >= 0.6
+                      else "latency-bound: no resource is above %.0f %% of its ceiling and the waves spend %.0f %% of their cycles at s_waitcnt "
+                           "(dependent node / primitive fetches served by %s)" % (100 * (limiter[0][1] or 0), 100 * waits, "L2 and beyond" if not nodes_in_lds else "LDS, L1 and L2")
+                      if waits >= 0.5 else "mixed: vector issue %.0f %%, waits %.0f %% of wave cycles" % (100 * roof["valu"]["busy"], 100 * waits))
+            roof["limiter"] = {"resource": top, "frac": limiter[0][1], "ranked": limiter, "regime": regime,
                                "note": "bound = this ranking's first entry; hbm and valu are counter measurements, l2 and lds are the algorithmic bytes those levels serve over their peaks"}
         else:
             # no counters in this run (N > 1, --no-pmc, or a pass failed): nothing measured to name a bound with. The contract's figure

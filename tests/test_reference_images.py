@@ -43,9 +43,10 @@ def test_final_scene_agrees_with_the_reference_image_in_the_large(rt, O):
     lit_a, dark_a = A[5:, :].mean(), A[1:4, 6:].mean()
     lit_b, dark_b = B[5:, :].mean(), B[1:4, 6:].mean()
     assert lit_a > 3 * dark_a and lit_b > 2 * dark_b
-    # exposure: the reference's image carries a floor of ~25 levels in its darkest blocks that v1's black background
-    # (book camera and background, not in v1's main.rs) does not have; above it the two agree
-    assert abs((A.mean() + 20.0) - B.mean()) < 15.0, (A.mean(), B.mean())
+    # exposure: the reference's image carries a floor in its darkest blocks (27 levels) that v1's black background (SURVEY.md
+    # §8c-3: book camera and background, not in v1's main.rs) does not have (7 levels). No fitted constant: each
+    # image's floor is read off the image itself — its darkest block — and what lies above the floor agrees (measured: 1.9 levels apart)
+    assert abs((A.mean() - A.min()) - (B.mean() - B.min())) < 8.0, (A.mean(), A.min(), B.mean(), B.min())
     # the earth texture (left, rows 4-5) is blue-green in both: blue and green exceed red there
     for im in (img, ref):
         patch = np.asarray(im[400:560, 40:200], dtype=np.float64).mean(axis=(0, 1))

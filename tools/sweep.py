@@ -23,8 +23,8 @@ dev = rt.DeviceScene(s.desc)
 pc = rt.make_params(W, H, 20, 50, bg, seed=2022, spp_chunk=1)
 out, st = dev.render(cam, pc, rows, want_stats=True)
 rays = st.rays * (spp / 20.0)
-def Q(q=18, segs=8, shift=2):
-    return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (1 << 24)
+def Q(q=18, segs=8, shift=2, groups=1):
+    return q | (1 << 8) | (2 << 12) | (segs << 16) | (shift << 20) | (groups << 24)
 cfgs = [('q%d' % q, Q(q=q)) for q in (8, 12, 16, 18, 20, 24, 28, 32, 40)] + [('segs%d' % g, Q(segs=g)) for g in (4, 8)] + [('shift%d' % h, Q(shift=h)) for h in (0, 1, 2, 3, 4, 5)]
 # vote weights (nibbles from the lowest: node, sphere, rect, box, medium, misc, ctx, done); 0 = the engine's default
 def WT(node=2, sphere=4, rect=4, box=4, medium=4, misc=4, ctx=4, done=2):
@@ -41,6 +41,11 @@ for rep in range(2):
             dev.set_tuning(q)
             ms = run(dev, cam, p, rows, W)
             print('%-8s %8.1f ms  %7.1f Mrays/s' % (tag, ms, rays / ms / 1e3), flush=True)
+    if which in ('groups', 'all'):         # groups of segments alternating their passes on streams of their own: one group's trace pass beside another's shade pass
+        for g in (1, 2, 3, 4, 6, 8):
+            dev.set_tuning(Q(groups=g))
+            ms = run(dev, cam, p, rows, W)
+            print('groups%-2d %8.1f ms  %7.1f Mrays/s' % (g, ms, rays / ms / 1e3), flush=True)
     if which in ('weights', 'all'):
         for tag, wt in wcfgs:
             dev.set_tuning(Q(), wt)
