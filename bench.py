@@ -1,24 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the path-tracing hot loop on MI355X.
 
-One step = one pass of the hot path over one frame's worth of rows per GPU:
-the book-2 final scene at 800x800x1000 spp (BASELINE.json's metric config) with the
-scene, camera and row list already resident in HBM. At N GPUs the default job is an
-N-frame film strip whose rows are dealt cyclically to the ranks (weak scaling,
-raytracer_2022_amd/film.py); `--scaling strong` splits ONE frame's rows over the
-ranks instead (BASELINE configs 4 and 5). The only exchange is the gather of the
-row buffers.
+One step = one pass of the hot path over one frame's worth of rows per GPU: the book-2 final scene at 800x800x1000 spp
+(BASELINE.json's metric config; --config c1|c2|c4|c5|s1e4|s1e5|s1e6 for the others) with the scene, camera and row list already
+resident in HBM. Steps are handed to the library up to four frames per rt_render_device call (an n-frame film strip: the path pool
+then drains once per call, not once per frame; every frame is bit-identical to the frame rendered alone). At N GPUs the default job
+is an N-frame strip per step whose rows are dealt cyclically to the ranks (weak scaling, raytracer_2022_amd/film.py); `--scaling
+strong` splits ONE frame's rows over the ranks instead (BASELINE configs 4 and 5). The only exchange is the gather of the row
+buffers. `python3 bench.py --gpus N` starts its own N rank processes (children, before this process touches the GPU); under
+torch.distributed.run it takes its rank from the environment.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      the dominant kernel (wf_trace) against the HBM roofline of SURVEY.md §8(d)
-                (algorithmic bytes per launch / mean launch duration from HIP events),
-                next to what the counters say really limits it: L2 bandwidth, VALU issue,
-                measured HBM traffic — every figure recomputable from the fields beside it
-  cpu_baseline  the CPU oracle on a bounded sample of the same workload, at the
-                reference's 8 threads (main.rs:40) and at all usable cores
-The PMC figures come from rocprofv3 passes this script runs on itself before it
-touches the GPU (N=1 only; `--no-pmc` skips them, and the traffic then falls back to
-the committed profile of the same workload, marked as such).
+  roofline      the dominant kernel (wf_trace). bound / achieved / peak / frac = the resource the counters of THIS run show closest to
+                its ceiling — the measured busy share of the vector issue slots, or the HBM bytes of FETCH_SIZE / WRITE_SIZE — with the
+                others ranked beside it (limiter); SURVEY.md §8(d)'s contractual figure (algorithmic bytes per launch / mean launch
+                duration from HIP events over the timed region / 8 TB/s) under contract_sec8d; every figure recomputable from the
+                fields beside it
+  cpu_baseline  the CPU oracle on a bounded sample of the same workload, at the reference's 8 threads (main.rs:40) and at all usable
+                cores (c1: also the whole frame)
+The PMC figures come from rocprofv3 passes this script runs on itself before it touches the GPU (N=1 only; `--no-pmc` skips them,
+and the traffic then falls back to the committed profile of the same workload, marked as such).
 """
 import argparse
 import csv
@@ -384,6 +385,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra steps without RT_FLAG_KERNEL_TIMES")
+    ap.add_argument("--partial-ring", type=int, default=0,
+                    help="planes of the library's partial-sum ring: 0 = its own choice (a ring when all spp planes of a call would exceed 64 GiB), -1 never, n force")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="steps (frames per GPU) handed to the library per rt_render_device call; default: min(4, steps, what keeps the call's partial sums under 100 GB)")
     ap.add_argument("--pmc-seconds", type=float, default=240.0, help="time budget of the counter passes")
@@ -461,6 +464,8 @@ def main():
     scene = rt.HostScene(scene_name, seed=args.seed, assets_dir=assets, param=SCENE_PARAM.get(args.config, 0))
     cam, bg = scene.default_view(W / H)
     dscene = rt.DeviceScene(scene.desc)
+    if args.partial_ring:
+        dscene.set_partial_ring(args.partial_ring)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -723,6 +728,7 @@ def main():
                        "scene": scene_name, "width": W, "height": H, "spp": spp, "max_depth": 50,
                        "frames": frames_per_step, "rows_per_gpu": n_rows, "spp_chunk": int(s.spp_chunk) if args.steps else args.spp_chunk,
                        "pool_slots": int(s.pool_slots) if args.steps else None, "seed": args.seed,
+                       "partial_sum_bytes_per_call": int(s.partial_bytes) if args.steps else None,
                        "steps_per_call": fpc, "calls": split(args.steps),
                        "steps_per_call_note": "a step is one frame per GPU; the library gets them %d at a time (one rt_render_device call = a %d-frame strip, frames keyed "
                                               "0..%d): its path pool drains once per call instead of once per frame; every frame's pixels are those of the frame rendered alone"

@@ -287,6 +287,9 @@ typedef struct rt_stats {
     uint64_t pool_slots;                          /* path slots of the wavefront pool the call ran with */
     double   trace_ms, shade_ms;                  /* RT_FLAG_KERNEL_TIMES: device time summed over the call's traversal (wf_trace) and
                                                      shading (wf_shade) launches; 0 otherwise */
+    uint64_t partial_bytes;                       /* HBM the call's per-sample partial sums took (spp_chunk > 0): 24 B x pixels x
+                                                     ceil(spp / spp_chunk), or 24 B x pixels x the planes of the ring the library
+                                                     switches to when that would exceed 64 GiB (same sums, bit for bit) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;     /* opaque: device-resident scene */

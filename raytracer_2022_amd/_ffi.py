@@ -143,7 +143,7 @@ class rt_stats(C.Structure):
                 ("prim_tests", C.c_uint64 * RT_KIND_COUNT), ("light_pdf_tests", C.c_uint64),
                 ("rng_draws", C.c_uint64), ("ms", C.c_double),
                 ("spp_chunk", C.c_uint32), ("passes", C.c_uint32), ("pool_slots", C.c_uint64),
-                ("trace_ms", C.c_double), ("shade_ms", C.c_double)]
+                ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("partial_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {"paths": self.paths, "rays": self.rays, "node_visits": self.node_visits,
@@ -164,7 +164,7 @@ ABI_SYMBOLS = [
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
     "rtb_last_error", "rtb_abi_sizes",
-    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe", "rt_debug_valu_probe",
+    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe", "rt_debug_valu_probe", "rt_debug_set_partial_ring",
 ]
 
 _lib = None
@@ -220,6 +220,7 @@ def lib():
     L.rt_debug_pass_timing.argtypes = [vp, P(dbl)]
     L.rt_debug_traffic_probe.argtypes = [C.c_int, u64, u64, u64]
     L.rt_debug_valu_probe.argtypes = [C.c_int, u32]
+    L.rt_debug_set_partial_ring.argtypes = [vp, C.c_int]
     _lib = L
     return L
 

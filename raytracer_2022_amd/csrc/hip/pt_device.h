@@ -88,6 +88,13 @@ struct RenderArgs {
     double *partial;                   // [n_chunks][n_pixels][3] (== out when n_chunks == 1)
     unsigned long long *work_counter;  // zeroed before launch
     double *tape;                      // bounce records: max_depth * 4 doubles per launched lane
+    // Ring of partial-sum planes (r3; one-sample work items only). 0: `partial` holds all n_chunks planes and chunk_sum adds
+    // them at the end. R > 0 (a power of two): work items are numbered sample-major (item = sample * n_pixels + pixel), sample c
+    // of a pixel goes to plane c mod R, the host adds finished planes to the output in sample order as the frame goes
+    // (ring_accumulate) and raises *claim_limit — the number of work items that may be handed out — behind them: R planes
+    // instead of spp, the same sums bit for bit (pixel_color += ..., main.rs:150, in sample order).
+    uint32_t ring;
+    const unsigned long long *claim_limit;
     uint32_t node_quorum;              // lanes that must want a node step for the fast path (1..64)
     uint32_t vote_weights;             // 4 bits per operation label: the vote picks max(lanes * weight)
     StatsDev *stats;                   // may be null
@@ -150,6 +157,11 @@ struct WfPool {
     uint32_t n_cus;         // compute units of the device (size of the persistent trace grid)
     uint32_t *n_active;     // [2] rays handed to the next trace pass, by pass parity (polled by the host)
     uint32_t *fault;        // [1] engine invariants found broken on the device (bit 0: a slot reached the shade pass untraced)
+    // Ring mode (RenderArgs::ring): the oldest work item still in flight after a shade pass, by pass parity (everything below
+    // it is finished: the host consumes the planes under it), and per segment the slots that asked for a work item and found
+    // the ring full: listed behind the segment's rays, with kind FRESH, so that the next shade pass asks again.
+    unsigned long long *oldest;     // [2]
+    uint32_t *starved_n;            // [n_blocks]
     // Pass-timing probe (rt_debug_pass_timing; null otherwise): {first wave start, last wave end, sum of
     // wave lifetimes, sum of wave time after the list ran dry, waves} in wall_clock64 ticks.
     unsigned long long *dbg;
@@ -198,7 +210,8 @@ struct WfStreams {
     hipStream_t stream[kMaxGroups] = {};
     hipEvent_t ev[kMaxGroups][2] = {};
     uint32_t *h_active = nullptr;      // pinned, [kMaxGroups][2]
-    unsigned long long *h_work = nullptr;   // pinned, [kMaxGroups][2]: the work counter as of the same batches (progress callback)
+    unsigned long long *h_work = nullptr;   // pinned, [kMaxGroups][2]: the work counter as of the same batches (progress callback, ring mode)
+    unsigned long long *h_oldest = nullptr; // pinned, [kMaxGroups][2]: WfPool::oldest as of the same batches (ring mode)
 };
 // rt_params::progress_cb as the engine sees it (host side only).
 struct Progress {
@@ -212,6 +225,7 @@ struct KernelTimes {
     std::vector<hipEvent_t> ev;        // grown on demand, reused from call to call
     double shade_ms = 0.0, trace_ms = 0.0;
 };
+struct RingCtl;                        // (below)
 // Wavefront engine: alternates shade / trace passes over the pool until it drains.
 // Blocks the calling thread (polls `n_active`). d_args is the device-resident copy of `args`.
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
@@ -220,8 +234,15 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                                    double *timing /* null, or [5]: see rt_debug_pass_timing */,
                                    uint32_t *out_fault /* WfPool::fault after the last pass */,
                                    KernelTimes *kt /* null, or where to put the per-kernel times (forces one group) */,
-                                   const Progress *progress = nullptr);
+                                   const Progress *progress = nullptr, const RingCtl *ring = nullptr);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
+// Ring mode: what launch_render_wavefront needs to consume planes as the frame goes.
+struct RingCtl {
+    uint32_t planes = 0;               // 0 = off
+    double *out = nullptr;             // [n_pixels * 3] the call's output: finished planes are added to it in sample order
+    unsigned long long *d_limit = nullptr;   // device word behind RenderArgs::claim_limit
+    uint32_t max_passes = 0;           // watchdog: more pass pairs than this is an engine error, not a long frame
+};
 hipError_t launch_tonemap(const double *rgb_sum, uint64_t n_pixels, int32_t spp, uint8_t *rgb8, hipStream_t stream);
 hipError_t launch_math_probe(int op, const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 hipError_t launch_rng_probe(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n, hipStream_t stream);

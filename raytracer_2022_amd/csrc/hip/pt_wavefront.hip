@@ -297,7 +297,9 @@ RT_DEV Vec3 texture_value_top(const SceneDev &s, uint32_t tex, uint32_t tex_kind
 #ifndef RT2022_SHADE_WAVES
 #define RT2022_SHADE_WAVES 3           // resident shade workgroups per CU = waves per SIMD (168 VGPRs; four: 128 VGPRs, 51 spilled)
 #endif
-template <bool STATS>
+// RING: the partial-sum ring of RenderArgs::ring is in use (a build of its own: the default instance carries none of its
+// bookkeeping — bounded claims, starved slots, the oldest item in flight).
+template <bool STATS, bool RING = false>
 __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const SceneDev s, const RenderArgs *__restrict__ ap, const WfPool pool, const uint32_t parity) {
     __shared__ uint32_t hist[SK_COUNT];
     __shared__ uint32_t cursor[SK_COUNT];
@@ -334,7 +336,10 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     // at the same position. Slots not on the list are idle. (Kinds live by list position, not by slot: the lanes of a
     // traversal wave take neighbouring entries, so their one-byte results land in the same cache lines at about the same
     // time instead of dirtying a line per byte all over the segment.)
-    const uint32_t n_listed = pool.list_n[blockIdx.x] < (uint32_t)S ? pool.list_n[blockIdx.x] : (uint32_t)S;
+    const uint32_t n_rays = pool.list_n[blockIdx.x] < (uint32_t)S ? pool.list_n[blockIdx.x] : (uint32_t)S;
+    // (ring mode: behind the rays sit the slots that found the ring full last pass, kind FRESH: they ask again now)
+    const uint32_t n_starved_in = RING ? (pool.starved_n[blockIdx.x] < (uint32_t)S - n_rays ? pool.starved_n[blockIdx.x] : (uint32_t)S - n_rays) : 0u;
+    const uint32_t n_listed = n_rays + n_starved_in;
     uint32_t my_kind[S / kBlock], my_slot[S / kBlock];
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
@@ -366,6 +371,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
     const bool small_job = a.n_items <= 0xFFFFFFFFull;
     const uint32_t step_shift = (a.node_quorum >> 20) & 0xFu;         // list class = expected steps >> shift (0 = slot order)
 
+    unsigned long long my_oldest = ~0ull;                            // (ring mode) the oldest work item among this thread's paths that go on
     for (uint32_t j0 = 0; j0 < total; j0 += kBlock) {
         const uint32_t j = j0 + tid;
         const bool on = j < total;
@@ -505,7 +511,12 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 Vec3 Lp(0.0, 0.0, 0.0);
                 if (!(nb >= 1 && !tainted && Lterm.x == 0.0 && Lterm.y == 0.0 && Lterm.z == 0.0)) Lp = tape.unwind(nb, Lterm);
                 if (single) {                                         // the item's one sample: 0 + L goes straight to its place
-                    double *o = a.partial + stt.item * 3;
+                    uint64_t place = stt.item;
+                    if (RING) {                                       // sample c of the pixel -> plane c mod R (c = the sample just finished: smp - 1)
+                        const uint64_t c = (uint64_t)(stt.smp - 1u);
+                        place = (c & (uint64_t)(a.ring - 1u)) * a.n_pixels + (stt.item - c * a.n_pixels);
+                    }
+                    double *o = a.partial + place * 3;
                     o[0] = 0.0 + Lp.x; o[1] = 0.0 + Lp.y; o[2] = 0.0 + Lp.z;   // pixel_color = 0; pixel_color += ..., main.rs:143,150
                 } else {
                     double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
@@ -535,6 +546,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
             }
         }
 
+        if (RING && on && alive) my_oldest = stt.item < my_oldest ? stt.item : my_oldest;
         if (on && alive) {
             cnt.ray();                                                // world.hit(r, 0.001, f64::MAX), main.rs:243
             pv.store_ray(slot, r, rng.s);
@@ -564,9 +576,30 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
 #define RT2022_ITEM_BATCH 1
 #endif
     __shared__ unsigned long long seg_items;
-    const bool batch = RT2022_ITEM_BATCH && single;
+    __shared__ uint32_t seg_take;        // (ring mode) how many of the n_want items the segment really got
+    __shared__ uint32_t seg_more;        // (ring mode) 1: work items remain beyond the ring's limit — the slots left without one ask again
+    const bool batch = (RT2022_ITEM_BATCH || RING) && single;
     if (batch) {
-        if (tid == 0) seg_items = n_want ? atomicAdd(a.work_counter, (unsigned long long)n_want) : 0ull;
+        if (tid == 0) {
+            if (!RING) {
+                seg_items = n_want ? atomicAdd(a.work_counter, (unsigned long long)n_want) : 0ull;
+            } else {
+                // Never beyond *claim_limit: sample c + R of a pixel shares its plane with sample c, which the host must have
+                // added to the output first (it raises the limit behind the planes it consumes, between passes).
+                const unsigned long long lim = *a.claim_limit;
+                unsigned long long old = atomicAdd(a.work_counter, 0ull);
+                uint32_t take = 0;
+                for (int tries = 0; tries < 64 && n_want; tries++) {
+                    take = old < lim ? (uint32_t)((unsigned long long)n_want < lim - old ? (unsigned long long)n_want : lim - old) : 0u;
+                    if (!take) break;
+                    const unsigned long long seen = atomicCAS(a.work_counter, old, old + take);
+                    if (seen == old) break;
+                    old = seen; take = 0;
+                }
+                seg_items = old; seg_take = take;
+                seg_more = old + take < a.n_items ? 1u : 0u;
+            }
+        }
         __syncthreads();
     }
     for (uint32_t j0 = 0; j0 < n_want; j0 += kBlock) {
@@ -575,6 +608,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         const uint32_t e = on ? (uint32_t)fresh_q[j] : 0u;
         const uint32_t slot = base + (e & 0x7FFFu);                   // (bit 15 is the flag; a segment holds at most 32768 slots)
         bool alive = false;
+        bool starved = false;        // (ring mode) wanted a work item, found the ring full: asks again next pass
         Ray r;
         Rng rng;
         uint32_t depth = 0;
@@ -604,10 +638,27 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                     }
                     if (need) {
                         unsigned long long item = batch ? seg_items + j : wbase + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                        if (RING && j >= seg_take) {                    // the ring (or the work) ran out before this slot's turn
+                            item = a.n_items;
+                            starved = seg_more != 0u;
+                        }
                         if (item < a.n_items) {
                             uint64_t pix_slot, yi;
                             uint32_t chunk_id, px;
-                            if (small_job) {                            // (32-bit divisions where everything fits: the usual case)
+                            if (RING) {                                 // sample-major: item = sample * n_pixels + pixel
+                                if (small_job) {
+                                    const uint32_t np32 = (uint32_t)a.n_pixels;
+                                    chunk_id = (uint32_t)item / np32;
+                                    const uint32_t ps32 = (uint32_t)item - chunk_id * np32, y32 = ps32 / a.width;
+                                    px = ps32 - y32 * a.width;
+                                    pix_slot = ps32; yi = y32;
+                                } else {
+                                    chunk_id = (uint32_t)(item / a.n_pixels);
+                                    pix_slot = item - (uint64_t)chunk_id * a.n_pixels;
+                                    yi = pix_slot / a.width;
+                                    px = (uint32_t)(pix_slot - yi * a.width);
+                                }
+                            } else if (small_job) {                     // (32-bit divisions where everything fits: the usual case)
                                 const uint32_t ps32 = (uint32_t)item / a.n_chunks, y32 = ps32 / a.width;
                                 chunk_id = (uint32_t)item - ps32 * a.n_chunks;
                                 px = ps32 - y32 * a.width;
@@ -662,20 +713,34 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 store_state(pool, slot, stt, true);
                 new_kind[slot - base] = (uint8_t)SK_TRACE;            // (a camera ray goes with the short ones: list class 0)
                 new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
+                if (RING) my_oldest = stt.item < my_oldest ? stt.item : my_oldest;
+            } else if (RING && starved) {
+                new_kind[slot - base] = (uint8_t)SK_FRESH;            // (not a ray: listed behind the rays, see below)
             }
         }
     }
     SP_MARK(6);                                                      // 6: second sweep (new paths)
     // Paths handed to the trace pass (the host stops when the whole pool reports none).
     for (uint32_t k = tid; k < kListBins; k += kBlock) bins[k] = 0;
+    __shared__ uint32_t list_total, n_starved_out;
+    __shared__ unsigned long long seg_oldest;
+    if (RING && tid == 0) { n_starved_out = 0; seg_oldest = ~0ull; }
     __syncthreads();
     // The segment's ray list, longest expected traversal first (counting sort, 16 classes): the stragglers of
     // the trace pass then start early instead of keeping a few lanes busy after the list has run dry.
     uint32_t my_key[S / kBlock];
+    uint32_t my_starved[RING ? S / kBlock : 1];                        // (ring mode) place among the segment's starved slots, or none
+    if (RING) {                                                        // the oldest work item in flight, over the segment
+        unsigned long long v = my_oldest;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(v, d); v = o < v ? o : v; }
+        if (lane == 0 && v != ~0ull) atomicMin(&seg_oldest, v);
+    }
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++) {
         uint32_t e = new_kind[i * kBlock + tid];
         uint32_t key = kListBins;                                      // carries no ray
+        if (RING) my_starved[i] = e == (uint32_t)SK_FRESH ? atomicAdd(&n_starved_out, 1u) : 0xFFFFFFFFu;
         // (second key: rays that point into the same octant meet the boxes in a similar pattern, and the lanes of a
         // wave draw neighbouring list entries)
         // (new_oct: octant | origin class << 3 | quadrant << 6 — contiguous fields when every key is in use)
@@ -717,11 +782,28 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
         pool.list_n[blockIdx.x] = acc;
         // Rays handed on by this pass (the host stops a group when a pass reports none). Two counters take
         // turns, so each pass can clear the one the next pass will add to.
-        if (acc) atomicAdd(&pool.n_active[parity], acc);
+        uint32_t going = acc;
+        if (RING) {                                                    // (slots waiting for the ring keep the frame going too)
+            list_total = acc;
+            pool.starved_n[blockIdx.x] = n_starved_out;
+            going += n_starved_out;
+            if (seg_oldest != ~0ull) atomicMin(&pool.oldest[parity], seg_oldest);
+            if (blockIdx.x == 0) pool.oldest[parity ^ 1u] = ~0ull;
+        }
+        if (going) atomicAdd(&pool.n_active[parity], going);
         if (acc) atomicMax(&pool.max_list[parity], acc);
         if (blockIdx.x == 0) { pool.n_active[parity ^ 1u] = 0; pool.max_list[parity ^ 1u] = 0; *pool.next_chunk = 0; }
     }
     __syncthreads();
+    if (RING) {
+#pragma unroll
+        for (int i = 0; i < S / kBlock; i++)
+            if (my_starved[i] != 0xFFFFFFFFu) {
+                const uint32_t pos = base + list_total + my_starved[i];
+                pool.list[pos] = (uint16_t)((uint32_t)(i * kBlock) + tid);
+                pool.kind[pos] = (uint8_t)SK_FRESH;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < S / kBlock; i++)
         if (my_key[i] < kListBins) {
@@ -1612,11 +1694,25 @@ struct WfLaunch {
     StatsDev *stats;
     uint32_t blocks;            // segments of the group
     hipStream_t stream;
+    bool ring = false;          // RenderArgs::ring in use: the shade pass's ring build
 };
 template <bool STATS>
 static void launch_shade(const WfLaunch &w, uint32_t parity) {
-    hipLaunchKernelGGL((wf_shade<STATS>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
+    if (w.ring) hipLaunchKernelGGL((wf_shade<STATS, true>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
+    else hipLaunchKernelGGL((wf_shade<STATS, false>), dim3(w.blocks), dim3(kBlock), 0, w.stream, w.scene, w.d_args, w.pool, parity);
 }
+// Ring mode: out[i] = (first plane of the frame ? 0 : out[i]) + partial[first mod R][i] + ... in sample order — pixel_color += ...,
+// main.rs:150, continued where the last call of this kernel left off (chunk_sum_kernel's sum, taken a few planes at a time).
+__global__ void __launch_bounds__(256) ring_accumulate_kernel(const double *partial, double *out, uint64_t n_values, uint32_t first, uint32_t count, uint32_t ring) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_values; i += stride) {
+        double acc = first == 0 ? 0.0 : out[i];
+        for (uint32_t c = first; c < first + count; c++) acc += partial[(uint64_t)(c & (ring - 1u)) * n_values + i];
+        out[i] = acc;
+    }
+}
+__global__ void ring_set_limit_kernel(unsigned long long *limit, unsigned long long value) { *limit = value; }
 template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false>
 static void launch_trace(const WfLaunch &w, uint32_t parity) {
     // A persistent grid: as many workgroups as the kernel's launch bounds keep resident, never more than the work
@@ -1718,10 +1814,28 @@ static void launch_pass(const WfLaunch &w, uint32_t parity, uint32_t stack_need,
 static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                 const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                 const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing, KernelTimes *kt,
-                                const Progress *progress) {
+                                const Progress *progress, const RingCtl *ring) {
     if (stack_need > (uint32_t)kStackLarge) return hipErrorInvalidValue;
     const bool report = progress && progress->cb && gs.h_work;
     unsigned long long reported = 0;
+    // Ring of partial-sum planes (RenderArgs::ring): planes consumed so far, and the claim limit that follows them.
+    const bool ringed = ring && ring->planes > 0 && args.ring == ring->planes && gs.h_work && gs.h_oldest;
+    if (ring && ring->planes > 0 && !ringed) return hipErrorInvalidValue;
+    uint32_t consumed = 0;
+    const uint64_t n_values = args.n_pixels * 3;
+    auto ring_limit = [&](uint32_t done) {
+        const unsigned long long lim = ((unsigned long long)done + ring->planes) * args.n_pixels;
+        return lim < args.n_items ? lim : (unsigned long long)args.n_items;
+    };
+    auto ring_consume = [&](uint32_t upto, hipStream_t st) -> hipError_t {          // planes [consumed, upto) are complete
+        if (upto <= consumed) return hipSuccess;
+        const uint64_t want = (n_values + 255) / 256;
+        hipLaunchKernelGGL(ring_accumulate_kernel, dim3((unsigned)(want > 2048 ? 2048 : (want ? want : 1))), dim3(256), 0, st,
+                           args.partial, ring->out, n_values, consumed, upto - consumed, ring->planes);
+        consumed = upto;
+        hipLaunchKernelGGL(ring_set_limit_kernel, dim3(1), dim3(1), 0, st, ring->d_limit, ring_limit(consumed));
+        return hipGetLastError();
+    };
     const uint32_t blocks = pool.n_blocks;
     hipError_t e;
     // Slots in use start FRESH (at most one work item per slot is ever needed at a time).
@@ -1735,9 +1849,15 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         if ((e = hipMemsetAsync(pool.n_active, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.max_list, 0, 2 * kMaxGroups * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(pool.fault, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+        if (ringed) {
+            if ((e = hipMemsetAsync(pool.oldest, 0xFF, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(pool.starved_n, 0, blocks * sizeof(uint32_t), stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(ring_set_limit_kernel, dim3(1), dim3(1), 0, stream, ring->d_limit, ring_limit(0));
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     }
     const uint32_t trace_blocks = blocks / pool.segs;
-    int G = (timing || kt) ? 1 : gs.n;
+    int G = (timing || kt || ringed) ? 1 : gs.n;
     if (G < 1) G = 1;
     if ((uint32_t)G > trace_blocks) G = (int)trace_blocks;
     WfLaunch w[kMaxGroups];
@@ -1755,7 +1875,7 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         v.n_active = pool.n_active + 2 * g;
         v.next_chunk = pool.next_chunk + g;
         v.max_list = pool.max_list + 2 * g;
-        w[g] = WfLaunch{scene, v, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, n_segs, G == 1 ? stream : gs.stream[g]};
+        w[g] = WfLaunch{scene, v, d_args, args.t_min, args.node_quorum, args.vote_weights, args.stats, n_segs, G == 1 ? stream : gs.stream[g], ringed};
     }
     if (G > 1) {                                // the groups start after what the caller's stream holds so far
         if ((e = hipEventRecord(gs.ev[0][0], stream)) != hipSuccess) return e;
@@ -1793,7 +1913,9 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         const uint32_t b = batches[g]++ & 1u;   // ring of two: batches of a group complete in order
         if ((e = hipMemcpyAsync(gs.h_active + 2 * g + b, w[g].pool.n_active + ((iter[g] - 1) & 1u), sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
-        if (report && (e = hipMemcpyAsync(gs.h_work + 2 * g + b, args.work_counter, sizeof(unsigned long long),
+        if ((report || ringed) && (e = hipMemcpyAsync(gs.h_work + 2 * g + b, args.work_counter, sizeof(unsigned long long),
+                                                      hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
+        if (ringed && (e = hipMemcpyAsync(gs.h_oldest + 2 * g + b, w[g].pool.oldest + ((iter[g] - 1) & 1u), sizeof(unsigned long long),
                                           hipMemcpyDeviceToHost, w[g].stream)) != hipSuccess) return e;
         return hipEventRecord(gs.ev[g][b], w[g].stream);
     };
@@ -1848,6 +1970,16 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
                                 (double)h[2] / (double)h[4] / (double)(h[1] - h[0]), (double)h[3] / (double)(h[2] ? h[2] : 1), h[4], gs.h_active[2 * g + b]);
                 }
             }
+            if (ringed) {
+                // Everything below the oldest item in flight (and below the counter: items not handed out yet are not in flight
+                // either) is finished: whole planes under that frontier go to the output, and the limit follows them. (The words
+                // were copied behind the batch's last shade pass; the kernels launched here run behind the batches already queued,
+                // whose claims still obey the old limit.)
+                unsigned long long frontier = gs.h_work[2 * g + b] < args.n_items ? gs.h_work[2 * g + b] : (unsigned long long)args.n_items;
+                if (gs.h_oldest[2 * g + b] < frontier) frontier = gs.h_oldest[2 * g + b];
+                if ((e = ring_consume((uint32_t)(frontier / args.n_pixels), w[g].stream)) != hipSuccess) return e;
+                if (ring->max_passes && iterations > ring->max_passes) return hipErrorUnknown;     // (a frame cannot take this long: never spin)
+            }
             if (gs.h_active[2 * g + b] == 0) {  // the batch's last shade pass handed no ray on: the group has drained
                 drained[g] = true;
                 live--;
@@ -1857,6 +1989,7 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
             if ((e = enqueue_batch(g)) != hipSuccess) return e;
         }
     }
+    if (ringed && (e = ring_consume(args.n_chunks, w[0].stream)) != hipSuccess) return e;      // (nothing is in flight any more)
     for (int g = 0; g < G; g++)                 // (a drained group may still have an idle batch queued)
         if ((e = hipStreamSynchronize(w[g].stream)) != hipSuccess) return e;
     if (kt) {                                   // device time of the shade passes and of the trace passes
@@ -1889,8 +2022,8 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,
                                    const WfPool &pool, uint32_t stack_need, unsigned features, bool counters,
                                    const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations, double *timing,
-                                   uint32_t *out_fault, KernelTimes *kt, const Progress *progress) {
-    hipError_t e = render_passes(scene, args, d_args, pool, stack_need, features, counters, gs, stream, out_iterations, timing, kt, progress);
+                                   uint32_t *out_fault, KernelTimes *kt, const Progress *progress, const RingCtl *ring) {
+    hipError_t e = render_passes(scene, args, d_args, pool, stack_need, features, counters, gs, stream, out_iterations, timing, kt, progress, ring);
     if (e != hipSuccess) {
         // Passes may still be queued or running against the pool on the group streams: let them finish (best
         // effort) before the caller sees the error and possibly frees or reuses the pool.

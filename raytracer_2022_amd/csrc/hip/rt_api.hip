@@ -292,6 +292,8 @@ struct Workspace {
     uint64_t used_slots = 0;
     uint32_t *rows_max = nullptr;     // device word: largest row id of the call being checked
     uint32_t *h_rows_max = nullptr;   // ... and the pinned word it is copied to
+    unsigned long long *d_limit = nullptr;   // ring mode: RenderArgs::claim_limit
+    uint64_t used_partial_bytes = 0;
 };
 
 } // namespace
@@ -309,6 +311,7 @@ struct rt_scene {
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
     int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
+    int partial_ring = 0;             // planes of the partial-sum ring: 0 automatic, -1 never, > 0 this many (rt_debug_set_partial_ring)
     double pass_timing[5] = {};       // of the last render with tuning bit 29 (rt_debug_pass_timing)
     int device = 0;
     int n_cus = 0;                    // compute units of `device`
@@ -356,6 +359,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
         RT_HIP(hipMalloc((void **)&w.d_pool, sizeof(WfPool)));
         RT_HIP(hipHostMalloc((void **)&w.gs.h_active, 2 * kMaxGroups * sizeof(uint32_t)));
         RT_HIP(hipHostMalloc((void **)&w.gs.h_work, 2 * kMaxGroups * sizeof(unsigned long long)));
+        RT_HIP(hipHostMalloc((void **)&w.gs.h_oldest, 2 * kMaxGroups * sizeof(unsigned long long)));
+        RT_HIP(hipMalloc((void **)&w.d_limit, sizeof(unsigned long long)));
         for (int g = 0; g < kMaxGroups; g++) {
             RT_HIP(hipStreamCreateWithFlags(&w.gs.stream[g], hipStreamNonBlocking));
             for (int b = 0; b < 2; b++) RT_HIP(hipEventCreateWithFlags(&w.gs.ev[g][b], hipEventDisableTiming));
@@ -387,6 +392,8 @@ void ensure_pool(Workspace &w, uint32_t blocks, uint32_t depth, hipStream_t stre
     q.next_chunk = pool_alloc<uint32_t>(w, kMaxGroups);
     q.max_list = pool_alloc<uint32_t>(w, 2 * kMaxGroups);
     q.fault = pool_alloc<uint32_t>(w, 1);
+    q.oldest = pool_alloc<unsigned long long>(w, 2);
+    q.starved_n = pool_alloc<uint32_t>(w, P / (uint64_t)kSlotsPerBlock);
     w.pool_dbg = pool_alloc<unsigned long long>(w, 8 + 2 * 65536);
     w.pool_slots = slots;
     w.pool_depth = depth;
@@ -442,8 +449,22 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     a.row_ids = d_rows;
     bool counters = stats && (p->flags & RT_FLAG_COUNTERS);
     const bool want_kt = stats && (p->flags & RT_FLAG_KERNEL_TIMES) && sc->engine == 1;
+    // Ring of partial-sum planes (pt_device.h, RenderArgs::ring): one-sample work items of the wavefront engine only. Automatic
+    // when all spp planes would take more than 64 GiB (C5: 99.5 GB): the largest power of two of planes that fits 16 GiB;
+    // rt_debug_set_partial_ring forces a size (tests: down to one plane) or switches it off.
+    a.ring = 0;
+    if (sc->engine == 1 && a.chunk == 1 && a.n_chunks > 1 && a.n_pixels > 0 && sc->partial_ring >= 0) {
+        uint32_t want = 0;
+        const uint64_t plane = a.n_pixels * 3 * sizeof(double);
+        if (sc->partial_ring > 0) want = (uint32_t)sc->partial_ring;
+        else if (a.n_items * 3 * sizeof(double) > (64ull << 30)) want = (uint32_t)std::max<uint64_t>(8, (16ull << 30) / plane);
+        uint32_t r = 0;
+        if (want) for (r = 1; r * 2u <= want && r < (1u << 30); r *= 2u) {}
+        if (r && r < a.n_chunks) a.ring = r;
+    }
     if (a.n_chunks > 1) {
-        uint64_t bytes = a.n_items * 3 * sizeof(double);
+        uint64_t bytes = (a.ring ? (uint64_t)a.ring * a.n_pixels : a.n_items) * 3 * sizeof(double);
+        w.used_partial_bytes = bytes;
         if (bytes > w.partial_bytes) {
             RT_HIP(hipStreamSynchronize(stream));
             if (w.partial) RT_HIP(hipFree(w.partial));
@@ -454,6 +475,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         a.partial = w.partial;
     } else {
         a.partial = d_out;
+        w.used_partial_bytes = 0;
     }
     // bit 31: boxes are plain (see wf_trace's fast path); bit 30 of the tuning word forces the literal step
     a.node_quorum = (sc->node_quorum & 0x7FFFFFFFu) | ((sc->boxes_plain && !(sc->node_quorum & (1u << 30))) ? (1u << 31) : 0u);
@@ -488,6 +510,7 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         if (blocks < segs) segs = blocks;
         blocks = blocks / segs * segs;
         ensure_pool(w, blocks, p->max_depth, stream);
+        a.claim_limit = w.d_limit;
         w.pool.segs = segs;
         w.pool.n_cus = (uint32_t)sc->n_cus;
         const bool timing = (sc->node_quorum & (1u << 29)) != 0;
@@ -511,12 +534,18 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         Progress prog;
         prog.cb = p->progress_cb; prog.user = p->progress_user;
         prog.total = a.n_pixels * p->spp; prog.per_item = a.chunk;
+        RingCtl ring;
+        ring.planes = a.ring; ring.out = d_out; ring.d_limit = w.d_limit;
+        // (watchdog of the ring's pass loop: a frame needs about items / slots pool fills of at most max_depth + 1 passes each)
+        // (... plus one drain per ring-full of planes when the ring is small)
+        ring.max_passes = (uint32_t)std::min<uint64_t>(1u << 26, 64 + 8 * (a.n_items / ((uint64_t)w.pool.n_blocks * kSlotsPerBlock) + 2 + (a.ring ? a.n_chunks / a.ring : 0)) *
+                                                                     ((uint64_t)p->max_depth + 2));
         if (a.n_items > 0) {
             uint32_t fault = 0;
             RT_HIP(launch_render_wavefront(sc->dev, a, w.d_args, w.pool, sc->stack_need, sc->features, counters, w.gs, stream, &w.iterations,
-                                           timing ? sc->pass_timing : nullptr, &fault, want_kt ? &w.kt : nullptr, &prog));
+                                           timing ? sc->pass_timing : nullptr, &fault, want_kt ? &w.kt : nullptr, &prog, a.ring ? &ring : nullptr));
             RT_REQUIRE(fault == 0, RT_ERR_DEVICE, "wavefront engine: a path slot reached the shade pass without having been traced (internal error; the frame is incomplete)");
-            if (a.n_chunks > 1) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
+            if (a.n_chunks > 1 && !a.ring) RT_HIP(launch_chunk_sum(a.partial, d_out, a.n_pixels * 3, a.n_chunks, stream));
         }
         RT_HIP(hipEventRecord(w.ev1, stream));
         w.pending = stats;
@@ -584,6 +613,7 @@ void finish(rt_scene *sc, hipStream_t stream) {
         RT_HIP(hipEventElapsedTime(&ms, w.ev0, w.ev1));
         out.ms = (double)ms;
         out.spp_chunk = w.used_chunk; out.passes = w.used_passes; out.pool_slots = w.used_slots;
+        out.partial_bytes = w.used_partial_bytes;
         if (w.used_kt) { out.trace_ms = w.kt.trace_ms; out.shade_ms = w.kt.shade_ms; }
         *w.pending = out;
         w.pending = nullptr;
@@ -757,6 +787,8 @@ int rt_scene_destroy(rt_scene *scene) {
             if (w.d_pool) (void)hipFree(w.d_pool);
             if (w.gs.h_active) (void)hipHostFree(w.gs.h_active);
             if (w.gs.h_work) (void)hipHostFree(w.gs.h_work);
+            if (w.gs.h_oldest) (void)hipHostFree(w.gs.h_oldest);
+            if (w.d_limit) (void)hipFree(w.d_limit);
             for (int g = 0; g < kMaxGroups; g++) {
                 if (w.gs.stream[g]) (void)hipStreamDestroy(w.gs.stream[g]);
                 for (int b = 0; b < 2; b++) if (w.gs.ev[g][b]) (void)hipEventDestroy(w.gs.ev[g][b]);
@@ -1135,6 +1167,15 @@ int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks) {
                    "the megakernel engine only handles media whose boundary is one primitive under movers");
         scene->engine = engine;
         scene->max_pool_blocks = max_pool_blocks;
+        return RT_OK;
+    });
+}
+
+int rt_debug_set_partial_ring(rt_scene *scene, int planes) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(scene, RT_ERR_INVALID, "rt_debug_set_partial_ring: null scene");
+        RT_REQUIRE(planes >= -1, RT_ERR_INVALID, "rt_debug_set_partial_ring: planes must be -1 (never), 0 (automatic) or a plane count");
+        scene->partial_ring = planes;
         return RT_OK;
     });
 }

@@ -31,6 +31,10 @@ class DeviceScene:
         """engine: "wavefront" (default) or "mega"."""
         F.check(F.lib().rt_debug_set_engine(self._h, {"mega": 0, "wavefront": 1}[engine], max_pool_blocks))
 
+    def set_partial_ring(self, planes):
+        """Planes of the partial-sum ring: 0 automatic, -1 never, n > 0 force (rt_debug_set_partial_ring)."""
+        F.check(F.lib().rt_debug_set_partial_ring(self._h, planes))
+
     def pass_timing(self):
         """Probe of the last render made with tuning bit 29: dict of sums over the traversal passes (ms)."""
         o = (C.c_double * 5)()

@@ -638,3 +638,56 @@ def test_frames_of_a_strip_are_the_frames_rendered_alone(rt, O):
     p1 = rt.make_params(W, H, spp, 50, bg, seed=2022, n_frames=1, spp_chunk=1)
     f0 = np.flatnonzero(strip_rows // H == 0)
     assert np.array_equal(bits(dev.render(cam, p1, strip_rows[f0])), bits(strip[f0]))
+
+
+@pytest.mark.parametrize("planes", [1, 2, 8, 64])
+def test_partial_sum_ring_gives_the_same_bits(rt, O, planes):
+    """Ring of partial-sum planes (one-sample work items, r3): sample c of a pixel goes to plane c mod R, the host adds finished
+    planes to the output in sample order while the frame runs, and work items beyond R planes wait. One plane makes every sample
+    wait for its predecessor (the worst case for the bookkeeping: starved slots, the claim limit, the oldest item in flight);
+    the sums must be the reference's running sums bit for bit whatever R is."""
+    W, H, spp = 64, 48, 40
+    s = rt.HostScene("final_scene", seed=2022)
+    cam, bg = s.default_view(W / H)
+    dev = rt.DeviceScene(s.desc)
+    p = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=1)
+    rows = rt.shuffled_rows(H, 2022)
+    dev.set_partial_ring(-1)
+    plain, st0 = dev.render(cam, p, rows, want_stats=True)
+    assert st0.partial_bytes == W * H * spp * 24
+    dev.set_partial_ring(planes)
+    ring, st1 = dev.render(cam, p, rows, want_stats=True)
+    assert st1.partial_bytes == W * H * planes * 24
+    assert st1.as_dict() == st0.as_dict()
+    assert np.array_equal(bits(ring), bits(plain))
+    again = dev.render(cam, p, rows)                                   # (the timed build of the kernels, not the counting one)
+    assert np.array_equal(bits(again), bits(plain))
+    ref = O.render_cpu(s.desc, cam, p, rows[:6], n_threads=4)
+    assert np.array_equal(bits(ring[:6]), bits(ref))
+    # a ring larger than spp is no ring; spp_chunk = 0 and k > 1 never use one
+    dev.set_partial_ring(1024)
+    _, st2 = dev.render(cam, p, rows, want_stats=True)
+    assert st2.partial_bytes == W * H * spp * 24
+    p4 = rt.make_params(W, H, spp, 50, bg, seed=2022, spp_chunk=4)
+    dev.set_partial_ring(2)
+    out4, st4 = dev.render(cam, p4, rows, want_stats=True)
+    assert st4.partial_bytes == W * H * 10 * 24
+    assert np.array_equal(bits(out4[:4]), bits(O.render_cpu(s.desc, cam, p4, rows[:4], n_threads=4)))
+
+
+def test_partial_sum_ring_on_a_strip_with_a_small_pool(rt, O):
+    """The ring under pressure: a three-frame strip, a pool of one segment (4096 slots for 27 648 pixels: many pool fills per
+    plane) and two planes — claims stall and resume all through the frame."""
+    W, H, spp, nf = 96, 96, 12, 3
+    s = rt.HostScene("cornell_box", seed=5)
+    cam, bg = s.default_view(1.0)
+    dev = rt.DeviceScene(s.desc)
+    from raytracer_2022_amd import film
+    rows = film.strip_rows(H, nf, 5)
+    p = rt.make_params(W, H, spp, 50, bg, seed=5, n_frames=nf, spp_chunk=1)
+    dev.set_partial_ring(-1)
+    plain = dev.render(cam, p, rows)
+    dev.set_engine("wavefront", 1)                                     # one segment of 4096 path slots
+    dev.set_partial_ring(2)
+    ring = dev.render(cam, p, rows)
+    assert np.array_equal(bits(ring), bits(plain))
