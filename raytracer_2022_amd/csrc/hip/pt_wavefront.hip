@@ -584,20 +584,19 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
             if (!RING) {
                 seg_items = n_want ? atomicAdd(a.work_counter, (unsigned long long)n_want) : 0ull;
             } else {
-                // Never beyond *claim_limit: sample c + R of a pixel shares its plane with sample c, which the host must have
-                // added to the output first (it raises the limit behind the planes it consumes, between passes).
+                // Never USE an item beyond *claim_limit: sample c + R of a pixel shares its plane with sample c, which the host must
+                // have added to the output first (it raises the limit behind the planes it consumes, between passes).
+                // One add, like the plain path (a compare-and-swap loop on one word shared by thousands of segments fails most
+                // of its tries: measured, a quarter of the frame); what lies beyond the limit is handed back. While a segment's
+                // surplus is out, other segments may see the counter too high and take nothing this pass — never too much: an
+                // item is only ever used by the segment whose add returned it, and only below the limit.
                 const unsigned long long lim = *a.claim_limit;
-                unsigned long long old = atomicAdd(a.work_counter, 0ull);
-                uint32_t take = 0;
-                for (int tries = 0; tries < 64 && n_want; tries++) {
-                    take = old < lim ? (uint32_t)((unsigned long long)n_want < lim - old ? (unsigned long long)n_want : lim - old) : 0u;
-                    if (!take) break;
-                    const unsigned long long seen = atomicCAS(a.work_counter, old, old + take);
-                    if (seen == old) break;
-                    old = seen; take = 0;
-                }
+                const unsigned long long old = n_want ? atomicAdd(a.work_counter, (unsigned long long)n_want) : 0ull;
+                const uint32_t take = old < lim ? (uint32_t)((unsigned long long)n_want < lim - old ? (unsigned long long)n_want : lim - old) : 0u;
+                const bool bound = lim < a.n_items;                 // the ring, not the end of the work, is what stops claims
+                if (bound && take < n_want) atomicAdd(a.work_counter, 0ull - (unsigned long long)(n_want - take));      // (minus: modulo 2^64)
                 seg_items = old; seg_take = take;
-                seg_more = old + take < a.n_items ? 1u : 0u;
+                seg_more = bound ? 1u : 0u;                          // (at lim == n_items nothing is handed back: beyond it the work IS done)
             }
         }
         __syncthreads();
