@@ -89,11 +89,14 @@ struct RenderArgs {
     unsigned long long *work_counter;  // zeroed before launch
     double *tape;                      // bounce records: max_depth * 4 doubles per launched lane
     // Ring of partial-sum planes (r3; one-sample work items only). 0: `partial` holds all n_chunks planes and chunk_sum adds
-    // them at the end. R > 0 (a power of two): work items are numbered sample-major (item = sample * n_pixels + pixel), sample c
-    // of a pixel goes to plane c mod R, the host adds finished planes to the output in sample order as the frame goes
-    // (ring_accumulate) and raises *claim_limit — the number of work items that may be handed out — behind them: R planes
-    // instead of spp, the same sums bit for bit (pixel_color += ..., main.rs:150, in sample order).
-    uint32_t ring;
+    // them at the end. R > 0: the samples are taken in GROUPS of ring_group consecutive ones (a divisor of spp, R a multiple of
+    // it): work items are numbered group-major — item = (group * n_pixels + pixel) * ring_group + sample within the group, so
+    // that the samples of a pixel in a group are still neighbours on the work counter (their camera rays stay coherent: plain
+    // sample-major order cost the traversal kernel 8 % on the headline and 30 % on C5) — sample c of a pixel goes to plane c mod R,
+    // the host adds finished groups of planes to the output in sample order as the frame goes (ring_accumulate) and raises
+    // *claim_limit — the number of work items that may be handed out — behind them: R planes instead of spp, the same sums bit
+    // for bit (pixel_color += ..., main.rs:150, in sample order).
+    uint32_t ring, ring_group;
     const unsigned long long *claim_limit;
     uint32_t node_quorum;              // lanes that must want a node step for the fast path (1..64)
     uint32_t vote_weights;             // 4 bits per operation label: the vote picks max(lanes * weight)
@@ -157,8 +160,8 @@ struct WfPool {
     uint32_t n_cus;         // compute units of the device (size of the persistent trace grid)
     uint32_t *n_active;     // [2] rays handed to the next trace pass, by pass parity (polled by the host)
     uint32_t *fault;        // [1] engine invariants found broken on the device (bit 0: a slot reached the shade pass untraced)
-    // Ring mode (RenderArgs::ring): the oldest work item still in flight after a shade pass, by pass parity (everything below
-    // it is finished: the host consumes the planes under it), and per segment the slots that asked for a work item and found
+    // Ring mode (RenderArgs::ring): the oldest sample GROUP with a path still in flight after a shade pass, by pass parity (every
+    // group below it is finished: the host consumes their planes), and per segment the slots that asked for a work item and found
     // the ring full: listed behind the segment's rays, with kind FRESH, so that the next shade pass asks again.
     unsigned long long *oldest;     // [2]
     uint32_t *starved_n;            // [n_blocks]

@@ -511,12 +511,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 Vec3 Lp(0.0, 0.0, 0.0);
                 if (!(nb >= 1 && !tainted && Lterm.x == 0.0 && Lterm.y == 0.0 && Lterm.z == 0.0)) Lp = tape.unwind(nb, Lterm);
                 if (single) {                                         // the item's one sample: 0 + L goes straight to its place
-                    uint64_t place = stt.item;
-                    if (RING) {                                       // sample c of the pixel -> plane c mod R (c = the sample just finished: smp - 1)
-                        const uint64_t c = (uint64_t)(stt.smp - 1u);
-                        place = (c & (uint64_t)(a.ring - 1u)) * a.n_pixels + (stt.item - c * a.n_pixels);
-                    }
-                    double *o = a.partial + place * 3;
+                    double *o = a.partial + stt.item * 3;                 // (ring mode: its plane is sample mod R — worked out when the path began)
                     o[0] = 0.0 + Lp.x; o[1] = 0.0 + Lp.y; o[2] = 0.0 + Lp.z;   // pixel_color = 0; pixel_color += ..., main.rs:143,150
                 } else {
                     double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
@@ -546,7 +541,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
             }
         }
 
-        if (RING && on && alive) my_oldest = stt.item < my_oldest ? stt.item : my_oldest;
+        if (RING && on && alive) { const unsigned long long grp = (stt.smp - 1u) / a.ring_group; my_oldest = grp < my_oldest ? grp : my_oldest; }      // (smp - 1: the sample in flight)
         if (on && alive) {
             cnt.ray();                                                // world.hit(r, 0.001, f64::MAX), main.rs:243
             pv.store_ray(slot, r, rng.s);
@@ -644,16 +639,17 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                         if (item < a.n_items) {
                             uint64_t pix_slot, yi;
                             uint32_t chunk_id, px;
-                            if (RING) {                                 // sample-major: item = sample * n_pixels + pixel
+                            if (RING) {                                 // group-major: item = (group * n_pixels + pixel) * ring_group + sample in the group
                                 if (small_job) {
-                                    const uint32_t np32 = (uint32_t)a.n_pixels;
-                                    chunk_id = (uint32_t)item / np32;
-                                    const uint32_t ps32 = (uint32_t)item - chunk_id * np32, y32 = ps32 / a.width;
+                                    const uint32_t q32 = (uint32_t)item / a.ring_group, np32 = (uint32_t)a.n_pixels;     // group * n_pixels + pixel
+                                    const uint32_t g32 = q32 / np32, ps32 = q32 - g32 * np32, y32 = ps32 / a.width;
+                                    chunk_id = g32 * a.ring_group + ((uint32_t)item - q32 * a.ring_group);
                                     px = ps32 - y32 * a.width;
                                     pix_slot = ps32; yi = y32;
                                 } else {
-                                    chunk_id = (uint32_t)(item / a.n_pixels);
-                                    pix_slot = item - (uint64_t)chunk_id * a.n_pixels;
+                                    const uint64_t q = item / a.ring_group, g = q / a.n_pixels;
+                                    chunk_id = (uint32_t)(g * a.ring_group + (item - q * a.ring_group));
+                                    pix_slot = q - g * a.n_pixels;
                                     yi = pix_slot / a.width;
                                     px = (uint32_t)(pix_slot - yi * a.width);
                                 }
@@ -673,7 +669,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                             uint32_t py = g - frame * a.height;
                             smp = chunk_id * a.chunk;
                             smp_end = smp + a.chunk < a.spp ? smp + a.chunk : a.spp;
-                            stt.item = (uint64_t)chunk_id * a.n_pixels + pix_slot;     // (kept as the item's place in the partial sums)
+                            stt.item = (uint64_t)(RING ? chunk_id % a.ring : chunk_id) * a.n_pixels + pix_slot;     // (kept as the item's place in the partial sums: ring mode, plane = sample mod R)
                             stt.px = px; stt.py = py; stt.frame = frame;
                             if (!single) {
                                 double2 *ps = reinterpret_cast<double2 *>(pool.pixel_sum + (uint64_t)slot * 4);
@@ -712,7 +708,7 @@ __global__ void __launch_bounds__(kBlock, RT2022_SHADE_WAVES) wf_shade(const Sce
                 store_state(pool, slot, stt, true);
                 new_kind[slot - base] = (uint8_t)SK_TRACE;            // (a camera ray goes with the short ones: list class 0)
                 new_oct[slot - base] = (uint8_t)(RT2022_LIST_OCTANTS ? ((r.dir.x < 0.0 ? 1u : 0u) | (r.dir.y < 0.0 ? 2u : 0u) | (r.dir.z < 0.0 ? 4u : 0u)) : 0u);
-                if (RING) my_oldest = stt.item < my_oldest ? stt.item : my_oldest;
+                if (RING) { const unsigned long long grp = (smp - 1u) / a.ring_group; my_oldest = grp < my_oldest ? grp : my_oldest; }
             } else if (RING && starved) {
                 new_kind[slot - base] = (uint8_t)SK_FRESH;            // (not a ray: listed behind the rays, see below)
             }
@@ -1707,7 +1703,7 @@ __global__ void __launch_bounds__(256) ring_accumulate_kernel(const double *part
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n_values; i += stride) {
         double acc = first == 0 ? 0.0 : out[i];
-        for (uint32_t c = first; c < first + count; c++) acc += partial[(uint64_t)(c & (ring - 1u)) * n_values + i];
+        for (uint32_t c = first; c < first + count; c++) acc += partial[(uint64_t)(c % ring) * n_values + i];
         out[i] = acc;
     }
 }
@@ -1818,12 +1814,14 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
     const bool report = progress && progress->cb && gs.h_work;
     unsigned long long reported = 0;
     // Ring of partial-sum planes (RenderArgs::ring): planes consumed so far, and the claim limit that follows them.
-    const bool ringed = ring && ring->planes > 0 && args.ring == ring->planes && gs.h_work && gs.h_oldest;
+    const bool ringed = ring && ring->planes > 0 && args.ring == ring->planes && gs.h_work && gs.h_oldest && args.ring_group > 0 &&
+                        args.ring % args.ring_group == 0 && args.n_chunks % args.ring_group == 0;
     if (ring && ring->planes > 0 && !ringed) return hipErrorInvalidValue;
-    uint32_t consumed = 0;
+    uint32_t consumed = 0;                      // planes added to the output so far (a multiple of the sample group)
     const uint64_t n_values = args.n_pixels * 3;
-    auto ring_limit = [&](uint32_t done) {
-        const unsigned long long lim = ((unsigned long long)done + ring->planes) * args.n_pixels;
+    const uint64_t per_group = ringed ? args.n_pixels * args.ring_group : 1;         // work items of one sample group
+    auto ring_limit = [&](uint32_t done) {      // the groups whose planes are free: those consumed, and R planes' worth beyond them
+        const unsigned long long lim = ((unsigned long long)done + ring->planes) / args.ring_group * per_group;
         return lim < args.n_items ? lim : (unsigned long long)args.n_items;
     };
     auto ring_consume = [&](uint32_t upto, hipStream_t st) -> hipError_t {          // planes [consumed, upto) are complete
@@ -1974,9 +1972,9 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
                 // either) is finished: whole planes under that frontier go to the output, and the limit follows them. (The words
                 // were copied behind the batch's last shade pass; the kernels launched here run behind the batches already queued,
                 // whose claims still obey the old limit.)
-                unsigned long long frontier = gs.h_work[2 * g + b] < args.n_items ? gs.h_work[2 * g + b] : (unsigned long long)args.n_items;
-                if (gs.h_oldest[2 * g + b] < frontier) frontier = gs.h_oldest[2 * g + b];
-                if ((e = ring_consume((uint32_t)(frontier / args.n_pixels), w[g].stream)) != hipSuccess) return e;
+                unsigned long long groups_done = (gs.h_work[2 * g + b] < args.n_items ? gs.h_work[2 * g + b] : (unsigned long long)args.n_items) / per_group;
+                if (gs.h_oldest[2 * g + b] < groups_done) groups_done = gs.h_oldest[2 * g + b];
+                if ((e = ring_consume((uint32_t)groups_done * args.ring_group, w[g].stream)) != hipSuccess) return e;
                 if (ring->max_passes && iterations > ring->max_passes) return hipErrorUnknown;     // (a frame cannot take this long: never spin)
             }
             if (gs.h_active[2 * g + b] == 0) {  // the batch's last shade pass handed no ray on: the group has drained

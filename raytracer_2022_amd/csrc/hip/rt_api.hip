@@ -452,15 +452,22 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     // Ring of partial-sum planes (pt_device.h, RenderArgs::ring): one-sample work items of the wavefront engine only. Automatic
     // when all spp planes would take more than 64 GiB (C5: 99.5 GB): the largest power of two of planes that fits 16 GiB;
     // rt_debug_set_partial_ring forces a size (tests: down to one plane) or switches it off.
-    a.ring = 0;
+    a.ring = 0; a.ring_group = 1;
     if (sc->engine == 1 && a.chunk == 1 && a.n_chunks > 1 && a.n_pixels > 0 && sc->partial_ring >= 0) {
         uint32_t want = 0;
         const uint64_t plane = a.n_pixels * 3 * sizeof(double);
         if (sc->partial_ring > 0) want = (uint32_t)sc->partial_ring;
         else if (a.n_items * 3 * sizeof(double) > (64ull << 30)) want = (uint32_t)std::max<uint64_t>(8, (16ull << 30) / plane);
-        uint32_t r = 0;
-        if (want) for (r = 1; r * 2u <= want && r < (1u << 30); r *= 2u) {}
-        if (r && r < a.n_chunks) a.ring = r;
+        if (want && want < a.n_chunks) {
+            // samples are taken in groups: the largest divisor of spp up to 64 (and up to a quarter of the ring, so that it holds
+            // a few groups); the ring is a whole number of groups
+            uint32_t grp = 1;
+            for (uint32_t d = 1; d <= 64 && d * 4u <= std::max(want, 4u); d++) if (a.n_chunks % d == 0) grp = d;
+            if (grp > want) grp = 1;
+            a.ring_group = grp;
+            a.ring = want / grp * grp;
+            if (a.ring == 0 || a.ring >= a.n_chunks) { a.ring = 0; a.ring_group = 1; }
+        }
     }
     if (a.n_chunks > 1) {
         uint64_t bytes = (a.ring ? (uint64_t)a.ring * a.n_pixels : a.n_items) * 3 * sizeof(double);

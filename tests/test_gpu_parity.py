@@ -640,7 +640,7 @@ def test_frames_of_a_strip_are_the_frames_rendered_alone(rt, O):
     assert np.array_equal(bits(dev.render(cam, p1, strip_rows[f0])), bits(strip[f0]))
 
 
-@pytest.mark.parametrize("planes", [1, 2, 8, 32])
+@pytest.mark.parametrize("planes", [1, 2, 8, 20, 32])
 def test_partial_sum_ring_gives_the_same_bits(rt, O, planes):
     """Ring of partial-sum planes (one-sample work items, r3): sample c of a pixel goes to plane c mod R, the host adds finished
     planes to the output in sample order while the frame runs, and work items beyond R planes wait. One plane makes every sample
