@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -312,6 +313,7 @@ struct rt_scene {
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
     int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
     int partial_ring = 0;             // planes of the partial-sum ring: 0 automatic, -1 never, > 0 this many (rt_debug_set_partial_ring)
+    int partial_ring_group = 0;       // largest sample group of the ring (0: 25); env RT2022_RING_GROUP at rt_scene_create (A/B)
     double pass_timing[5] = {};       // of the last render with tuning bit 29 (rt_debug_pass_timing)
     int device = 0;
     int n_cus = 0;                    // compute units of `device`
@@ -457,12 +459,15 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         uint32_t want = 0;
         const uint64_t plane = a.n_pixels * 3 * sizeof(double);
         if (sc->partial_ring > 0) want = (uint32_t)sc->partial_ring;
-        else if (a.n_items * 3 * sizeof(double) > (64ull << 30)) want = (uint32_t)std::max<uint64_t>(8, (16ull << 30) / plane);
+        else if (a.n_items * 3 * sizeof(double) > (64ull << 30)) want = (uint32_t)std::max<uint64_t>(8, (24ull << 30) / plane);
         if (want && want < a.n_chunks) {
-            // samples are taken in groups: the largest divisor of spp up to 64 (and up to a quarter of the ring, so that it holds
-            // a few groups); the ring is a whole number of groups
+            // samples are taken in groups: the largest divisor of spp up to 25 (and up to a quarter of the ring, so that it holds
+            // a few groups); the ring is a whole number of groups. (A group's planes are free again only when its last straggler
+            // has ended, ~60 passes after its first claim: the ring must hold what is claimed meanwhile — measured on C5: five
+            // groups of 50 stall every pool fill, twenty of 25 never.)
             uint32_t grp = 1;
-            for (uint32_t d = 1; d <= 64 && d * 4u <= std::max(want, 4u); d++) if (a.n_chunks % d == 0) grp = d;
+            const uint32_t group_max = sc->partial_ring_group > 0 ? (uint32_t)sc->partial_ring_group : 25u;
+            for (uint32_t d = 1; d <= group_max && d * 4u <= std::max(want, 4u); d++) if (a.n_chunks % d == 0) grp = d;
             if (grp > want) grp = 1;
             a.ring_group = grp;
             a.ring = want / grp * grp;
@@ -646,6 +651,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
         hipError_t e = hipGetDeviceCount(&ndev);
         RT_REQUIRE(e == hipSuccess && ndev > 0, RT_ERR_DEVICE, "rt_scene_create: no HIP device available (the path has no CPU fallback)");
         rt_scene *sc = new rt_scene();
+        if (const char *eg = getenv("RT2022_RING_GROUP")) sc->partial_ring_group = atoi(eg);
         try {
             RT_HIP(hipGetDevice(&sc->device));
             RT_HIP(hipDeviceGetAttribute(&sc->n_cus, hipDeviceAttributeMultiprocessorCount, sc->device));
