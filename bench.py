@@ -386,7 +386,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
     ap.add_argument("--no-plain", action="store_true", help="skip the extra steps without RT_FLAG_KERNEL_TIMES")
     ap.add_argument("--partial-ring", type=int, default=0,
-                    help="planes of the library's partial-sum ring: 0 = its own choice (a ring when all spp planes of a call would exceed 64 GiB), -1 never, n force")
+                    help="planes of the library's partial-sum ring: 0 = its own choice (a ring when all spp planes of a call would exceed 40 % of the device's memory), -1 never, n force")
     ap.add_argument("--frames-per-call", type=int, default=0,
                     help="steps (frames per GPU) handed to the library per rt_render_device call; default: min(4, steps, what keeps the call's partial sums under 100 GB)")
     ap.add_argument("--pmc-seconds", type=float, default=240.0, help="time budget of the counter passes")

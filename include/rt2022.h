@@ -289,7 +289,7 @@ typedef struct rt_stats {
                                                      shading (wf_shade) launches; 0 otherwise */
     uint64_t partial_bytes;                       /* HBM the call's per-sample partial sums took (spp_chunk > 0): 24 B x pixels x
                                                      ceil(spp / spp_chunk), or 24 B x pixels x the planes of the ring the library
-                                                     switches to when that would exceed 64 GiB (same sums, bit for bit) */
+                                                     switches to when that would exceed 40 % of the device's memory (same sums, bit for bit) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;     /* opaque: device-resident scene */

@@ -36,8 +36,8 @@ int rt_debug_set_tuning(rt_scene *scene, uint32_t node_quorum, uint32_t vote_wei
  * megakernel (pt_kernel.hip). max_pool_blocks: segments of 4096 path slots in the pool (0 = the default of the tuning word).
  * Results are bit-identical between the two; only speed differs. */
 int rt_debug_set_engine(rt_scene *scene, int engine, int max_pool_blocks);
-/* Partial-sum ring of the default engine (one-sample work items): planes = 0 automatic (a ring of at most 16 GiB when all spp
- * planes would exceed 64 GiB), -1 never, n > 0 force a ring of n planes (rounded down to a power of two; tests go down to one
+/* Partial-sum ring of the default engine (one-sample work items): planes = 0 automatic (a ring of at most 24 GiB when all spp
+ * planes would exceed 40 % of the device's memory), -1 never, n > 0 force a ring of n planes (rounded down to a power of two; tests go down to one
  * plane, where every sample waits for its predecessor). Memory and speed only: the sums are the same bit for bit. */
 int rt_debug_set_partial_ring(rt_scene *scene, int planes);
 /* Scheduler census of the last counter run (RT_FLAG_COUNTERS) of the wavefront traversal kernel:

@@ -314,6 +314,7 @@ struct rt_scene {
     int max_pool_blocks = 0;          // 0 = 5 x CUs x segments per trace workgroup
     int partial_ring = 0;             // planes of the partial-sum ring: 0 automatic, -1 never, > 0 this many (rt_debug_set_partial_ring)
     int partial_ring_group = 0;       // largest sample group of the ring (0: 25); env RT2022_RING_GROUP at rt_scene_create (A/B)
+    uint64_t ring_threshold_bytes = 64ull << 30;   // partial sums above this switch the ring on: 40 % of the device's memory (rt_scene_create)
     double pass_timing[5] = {};       // of the last render with tuning bit 29 (rt_debug_pass_timing)
     int device = 0;
     int n_cus = 0;                    // compute units of `device`
@@ -452,14 +453,15 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
     bool counters = stats && (p->flags & RT_FLAG_COUNTERS);
     const bool want_kt = stats && (p->flags & RT_FLAG_KERNEL_TIMES) && sc->engine == 1;
     // Ring of partial-sum planes (pt_device.h, RenderArgs::ring): one-sample work items of the wavefront engine only. Automatic
-    // when all spp planes would take more than 64 GiB (C5: 99.5 GB): the largest power of two of planes that fits 16 GiB;
-    // rt_debug_set_partial_ring forces a size (tests: down to one plane) or switches it off.
+    // when all spp planes would take more than 40 % of the device's memory (115 GB on an MI355X: C5's 99.5 GB stay below it —
+    // the ring's work-item order costs its traversal 10 %, the headline's 1.4 %: profiles/r3j_ring.log): then at most 24 GiB
+    // of planes; rt_debug_set_partial_ring forces a size (tests: down to one plane) or switches it off.
     a.ring = 0; a.ring_group = 1;
     if (sc->engine == 1 && a.chunk == 1 && a.n_chunks > 1 && a.n_pixels > 0 && sc->partial_ring >= 0) {
         uint32_t want = 0;
         const uint64_t plane = a.n_pixels * 3 * sizeof(double);
         if (sc->partial_ring > 0) want = (uint32_t)sc->partial_ring;
-        else if (a.n_items * 3 * sizeof(double) > (64ull << 30)) want = (uint32_t)std::max<uint64_t>(8, (24ull << 30) / plane);
+        else if (a.n_items * 3 * sizeof(double) > sc->ring_threshold_bytes) want = (uint32_t)std::max<uint64_t>(8, (24ull << 30) / plane);
         if (want && want < a.n_chunks) {
             // samples are taken in groups: the largest divisor of spp up to 25 (and up to a quarter of the ring, so that it holds
             // a few groups); the ring is a whole number of groups. (A group's planes are free again only when its last straggler
@@ -656,6 +658,10 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             RT_HIP(hipGetDevice(&sc->device));
             RT_HIP(hipDeviceGetAttribute(&sc->n_cus, hipDeviceAttributeMultiprocessorCount, sc->device));
             RT_REQUIRE(sc->n_cus > 0, RT_ERR_DEVICE, "rt_scene_create: device reports no compute units");
+            {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) sc->ring_threshold_bytes = (uint64_t)((double)total_b * 0.4);
+            }
             SceneDev &s = sc->dev;
             // Node refs of the device copy follow the breadth-first numbering (breadth_first_nodes).
             const std::vector<uint32_t> new_of = breadth_first_nodes(*desc);
