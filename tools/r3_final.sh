@@ -1,0 +1,13 @@
+#!/bin/bash
+# What the driver runs at round end, rehearsed: the GPU suite, smoke(), the default bench line.
+set -e
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r3k_pytest.log 2>&1 || { tail -40 gpurun_out/r3k_pytest.log; exit 1; }
+tail -2 gpurun_out/r3k_pytest.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout -k 10 600 python bench.py > gpurun_out/r3k_bench_default.json 2> gpurun_out/r3k_bench_default.err || { tail -5 gpurun_out/r3k_bench_default.err; exit 1; }
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/r3k_bench_default.json').read().strip().splitlines()[-1]); r=d['roofline']
+print(d['metric'], d['value'], d['unit'], d['ms_per_step'], 'steps', d['steps'], 'calls', d['config']['calls'], 'bound', r['bound'], r['frac'], 'sec8d', r['contract_sec8d']['frac'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'plain', d['plain_path']['value'])"
