@@ -836,6 +836,9 @@ struct TLane {
     uint32_t win_mat;      // material word of the winning leaf (index | slot kind << kMatKindShift), taken from the record at hand
     double stash_ix, stash_iz;   // 1/d.x, 1/d.z of the frame a RotateY was entered from (they change only there) ...
     uint32_t stash_level;        // ... and that frame's mover depth (0xFFFFFFFF: nothing stashed)
+    // (node table in LDS, RT2022_SIGNED_SLABS) byte addresses, within the table's record 0, of the box coordinate the ray meets
+    // first / last on each axis: bmin / bmax by the sign of 1/d — set wherever inv is (t_slabs)
+    uint32_t near_at[3], far_at[3];
     uint32_t slot;
     uint32_t entry;        // where on the ray list the slot was found (its kind goes back to the same place)
     uint32_t steps;        // node steps of this ray
@@ -865,6 +868,16 @@ RT_DEV void t_flags(TLane &L, bool boxes_plain) {
     const bool plain = boxes_plain && t_finite(L.inv.x) && t_finite(L.inv.y) && t_finite(L.inv.z) && L.inv.x != 0.0 && L.inv.y != 0.0 &&
               L.inv.z != 0.0 && t_finite(L.cur.o.x) && t_finite(L.cur.o.y) && t_finite(L.cur.o.z);
     t_flag(L, kPlain, plain);
+}
+// For a plain ray the slab test's min(t0, t1) / max(t0, t1) per axis IS the choice of bmin or bmax by the sign of 1/d (the
+// products are ordered by it: see the fast path) — made here once per direction instead of twice per axis and node step.
+RT_DEV void t_slabs(TLane &L, uint32_t table_at) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const bool neg = L.inv[i] < 0.0;
+        L.near_at[i] = table_at + (neg ? 24u : 0u) + 8u * (uint32_t)i;          // record: bmin x y z at +0 +8 +16, bmax at +24 +32 +40
+        L.far_at[i] = table_at + (neg ? 0u : 24u) + 8u * (uint32_t)i;
+    }
 }
 RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
@@ -1133,11 +1146,17 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     unsigned long long ctab = kClassifyTable;
     uint32_t ref_empty = REF_EMPTY;
     asm volatile("" : "+s"(ctab), "+v"(ref_empty));                  // (a select takes one scalar operand, and that is its lane mask)
+#ifndef RT2022_SIGNED_SLABS
+#define RT2022_SIGNED_SLABS 1          // node table in LDS: the near / far box coordinate of each axis fetched by the sign of 1/d (no min / max per axis)
+#endif
+    constexpr bool kSlabs = RT2022_SIGNED_SLABS && CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc);      // (a partial table mixes both sources in one wave; the triangle kernels have no six registers to spare)
     typedef const __attribute__((address_space(3))) f64x2 *LdsBoxPtr;
     typedef const __attribute__((address_space(3))) u32x2 *LdsRefPtr;
     LdsBoxPtr ncb = (LdsBoxPtr)nc_box;
     LdsRefPtr ncr = (LdsRefPtr)nc_ref;
     if (CACHE > 0) asm volatile("" : "+v"(ncb), "+v"(ncr));
+    const uint32_t table_at = (uint32_t)(uintptr_t)ncb;              // (LDS byte address of node record 0's box)
+    L.near_at[0] = L.near_at[1] = L.near_at[2] = L.far_at[0] = L.far_at[1] = L.far_at[2] = table_at;
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to — nn >= the quorum. Below the quorum the vote
@@ -1186,12 +1205,23 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     // The five LDS reads of a node step, issued back to back and waited for ONCE — written out, because the compiler's
                     // own placement of the waits split them (seen in the ISA: the child refs were waited for before the box was even
                     // asked for: two LDS round trips per node step instead of one).
-                    f64x2 c0, c1, c2;
                     u32x2 cr;
-                    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
-                                 "ds_read_b64 %3, %6\n\tds_read_b32 %4, %7\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(cr), "=&v"(below) : "v"(box_at), "v"(ref_at), "v"(below_at) : "memory");
-                    bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
+                    if (kSlabs) {
+                        // bmin[] / bmax[] here are the coordinates the ray meets FIRST / LAST on each axis (bmin or bmax by the sign of
+                        // 1/d: t_slabs): for a plain ray min(t0, t1) is the product with the first, max(t0, t1) with the last.
+                        const uint32_t off = __umul24(L.top, 48u);
+                        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(bmin[0]), "=&v"(bmin[1]), "=&v"(bmin[2]), "=&v"(bmax[0]), "=&v"(bmax[1]), "=&v"(bmax[2]), "=&v"(cr), "=&v"(below)
+                                     : "v"(L.near_at[0] + off), "v"(L.near_at[1] + off), "v"(L.near_at[2] + off), "v"(L.far_at[0] + off), "v"(L.far_at[1] + off),
+                                       "v"(L.far_at[2] + off), "v"(ref_at), "v"(below_at) : "memory");
+                    } else {
+                        f64x2 c0, c1, c2;
+                        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\t"
+                                     "ds_read_b64 %3, %6\n\tds_read_b32 %4, %7\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(cr), "=&v"(below) : "v"(box_at), "v"(ref_at), "v"(below_at) : "memory");
+                        bmin[0] = c0.x; bmin[1] = c0.y; bmin[2] = c1.x; bmax[0] = c1.y; bmax[1] = c2.x; bmax[2] = c2.y;
+                    }
                     left = cr.x; right = cr.y;
                 } else {
                     const uint4 *np = reinterpret_cast<const uint4 *>(s.nodes + nidx);
@@ -1208,7 +1238,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 for (int i = 0; i < 3; i++) {
                     double t0 = (bmin[i] - L.cur.o[i]) * L.inv[i];
                     double t1 = (bmax[i] - L.cur.o[i]) * L.inv[i];
-                    const double lo = __builtin_fmin(t0, t1), hi = __builtin_fmax(t0, t1);
+                    constexpr bool sorted = kSlabs;                               // (t0 <= t1 already: the coordinates came in that order)
+                    const double lo = sorted ? t0 : __builtin_fmin(t0, t1), hi = sorted ? t1 : __builtin_fmax(t0, t1);
                     // fmax / fmin of a value that is not an arithmetic result of the same block first "canonicalises" it (a
                     // v_max_f64 x, x) — per node step, for the window's two ends, which never change in here. Written as the
                     // instruction fmax / fmin compile to; no operand is a NaN on this path (see above), so it is the same value.
@@ -1515,6 +1546,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     L.a_len = L.cur.d.length_sqr();
                 }
                 t_flags(L, boxes_plain);
+                if (kSlabs) t_slabs(L, table_at);
                 T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -1542,6 +1574,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                         L.cur.o = L.cur.o / p0;
                     }
                     t_flags(L, boxes_plain);
+                    if (kSlabs) t_slabs(L, table_at);
                     L.ctx.push(L.top);
                     st.push(L, REF_POPCTX);
                     L.top = x0.y;
@@ -1626,6 +1659,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
+                if (kSlabs) t_slabs(L, table_at);
                 if (FEAT & kFeatMovers) L.stash_level = 0xFFFFFFFFu;
                 if (kStash) {                                         // what leaving a mover goes back to (OP_CTX)
                     wray[0 * WG] = wr.orig.x; wray[1 * WG] = wr.orig.y; wray[2 * WG] = wr.orig.z;
