@@ -1200,7 +1200,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                     // (LDS addresses are 32 bits and a table index is far below 2^24: one v_mad_u32_u24 instead of a 64-bit multiply-add)
                     // (the 24-bit multiply-add takes the low 24 bits of the ref: its index, un-masked)
-                    const uint32_t box_at = (uint32_t)(uintptr_t)ncb + __umul24(L.top, 48u), ref_at = (uint32_t)(uintptr_t)ncr + __umul24(L.top, 8u);
+                    const uint32_t box_at = (uint32_t)(uintptr_t)ncb + __umul24(L.top, 48u);
+                    uint32_t ref_at;
+                    asm("v_mad_u32_u24 %0, %1, 8, %2" : "=v"(ref_at) : "v"(L.top), "v"((uint32_t)(uintptr_t)ncr));     // (one instruction; left alone the compiler masks, shifts and adds)
                     const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
                     // The five LDS reads of a node step, issued back to back and waited for ONCE — written out, because the compiler's
                     // own placement of the waits split them (seen in the ISA: the child refs were waited for before the box was even
