@@ -860,7 +860,7 @@ struct TStack {
     RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * WG]; } return REF_EMPTY; }
 };
 
-constexpr uint32_t kPlain = 1u, kHasRay = 2u, kSubFound = 4u, kTouched = 8u;      // kTouched: the leaf at L.top has had its record asked for (RT2022_LEAF_TOUCH)
+constexpr uint32_t kPlain = 1u, kHasRay = 2u, kSubFound = 4u;
 RT_DEV void t_flag(TLane &L, uint32_t bit, bool on) { L.flags = on ? (L.flags | bit) : (L.flags & ~bit); asm volatile("" : "+v"(L.flags)); }
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
 // The fast node step applies (see there): every 1/d finite and non-zero, origin finite, boxes plain.
@@ -1271,21 +1271,6 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             if (entered) L.op = classify(L.top, ctab);                // (media met in there start in their own arm)
         }
         TP_MARK(0);
-#ifndef RT2022_LEAF_TOUCH
-#define RT2022_LEAF_TOUCH 0
-#endif
-        // A triangle that has just come up (RT2022_LEAF_TOUCH; meshes beyond L2 only make sense): its lane now waits for the
-        // vote, and when the arm comes its 80-byte record is two dependent memory round trips away. Ask for both of its cache
-        // lines at once, now — the loads' results are never used; the arm's own fetch then finds them on their way or in L2.
-        // (A load the compiler does not know of can only make its s_waitcnt counts stricter: vmcnt returns in order.)
-        if (RT2022_LEAF_TOUCH && (FEAT & kFeatMisc)) {
-            if (L.op == OP_MISC && !(L.flags & kTouched) && RT_REF_KIND(L.top) == RT_KIND_TRIANGLE) {
-                const char *tp = reinterpret_cast<const char *>(s.triangles + RT_REF_INDEX(L.top));
-                uint32_t w0, w1;
-                asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:64" : "=v"(w0), "=v"(w1) : "v"(tp) : "memory");
-                L.flags |= kTouched;
-            }
-        }
         // Vote: the label most lanes are waiting on (ties -> lowest id).
         int best = -1, best_n = 0;
 #pragma unroll
@@ -1529,6 +1514,15 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 const f64x2 *qp = reinterpret_cast<const f64x2 *>(s.triangles + idx);
                 f64x2 q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3], q4 = qp[4];
                 t_pin(q0); t_pin(q1); t_pin(q2); t_pin(q3); t_pin(q4);
+#ifdef RT2022_WHATIF_TRI_FETCH
+                {   // (diagnostic build: the record fetched a second time behind the first — what is one memory round trip of this arm worth?)
+                    uint32_t z;
+                    asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"((uint32_t)rtm::d2u(q0.x)));
+                    const f64x2 *qp2 = reinterpret_cast<const f64x2 *>(s.triangles + (idx + z));
+                    q0 = qp2[0]; q1 = qp2[1]; q2 = qp2[2]; q3 = qp2[3]; q4 = qp2[4];
+                    t_pin(q0); t_pin(q1); t_pin(q2); t_pin(q3); t_pin(q4);
+                }
+#endif
                 rt_triangle tr;
                 tr.a[0] = q0.x; tr.a[1] = q0.y; tr.a[2] = q1.x; tr.b[0] = q1.y; tr.b[1] = q2.x; tr.b[2] = q2.y;
                 tr.c[0] = q3.x; tr.c[1] = q3.y; tr.c[2] = q4.x;
@@ -1539,7 +1533,6 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 h = ring_t(s.rings[idx], L.cur, L.t_lo, t_hi(L), t);
             }
             if (h) t_accept(L, t, 0, mat_word);
-            if (RT2022_LEAF_TOUCH) L.flags &= ~kTouched;
             T_NEXT();
             }
         } else if ((FEAT & kFeatMovers) && best == OP_CTX) {                                  // movers in / out, HittableList expansion
