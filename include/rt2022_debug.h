@@ -68,6 +68,13 @@ int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *gr
  * node fetched through L1 / L2), and whether its Sphere / MovingSphere pools are there too (1: small sphere-only scenes). */
 int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds,
                            uint32_t *spheres_in_lds);
+/* The single-precision slab test of the traversal kernel for sphere-only scenes: out[3] = the build's
+ * RT2022_F32_SLABS (0 off, 1 the all-in-LDS instance of sphere-only scenes, 2 every instance that keeps the whole node table
+ * in LDS). A diagnostic build (-DRT2022_F32_CENSUS, out[2] = 1) also makes the double-precision test beside every verdict
+ * the single-precision one takes and counts, over all renders since the last call: out[0] node steps of the fast path that
+ * took the single-precision test, out[1] those it left undecided, out[4] verdicts that differed (must be 0). The call clears
+ * the counters. */
+int rt_debug_f32_slabs(uint64_t out[5]);
 
 #ifdef __cplusplus
 }

@@ -164,7 +164,7 @@ ABI_SYMBOLS = [
     "rtb_scene_build", "rtb_scene_free", "rtb_scene_desc", "rtb_scene_default_view", "rtb_camera_new",
     "rtb_shuffled_rows", "rtb_bvh_build", "rtb_fill_image", "rtb_write_ppm", "rtb_write_jpeg", "rtb_image_load",
     "rtb_last_error", "rtb_abi_sizes",
-    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe", "rt_debug_valu_probe", "rt_debug_set_partial_ring",
+    "rt_debug_math_device", "rt_debug_rng_device", "rt_debug_scene_info", "rt_debug_trace_variant", "rt_debug_set_tuning", "rt_debug_set_engine", "rt_debug_census", "rt_debug_pass_timing", "rt_debug_traffic_probe", "rt_debug_valu_probe", "rt_debug_set_partial_ring", "rt_debug_f32_slabs",
 ]
 
 _lib = None
@@ -221,6 +221,7 @@ def lib():
     L.rt_debug_traffic_probe.argtypes = [C.c_int, u64, u64, u64]
     L.rt_debug_valu_probe.argtypes = [C.c_int, u32]
     L.rt_debug_set_partial_ring.argtypes = [vp, C.c_int]
+    L.rt_debug_f32_slabs.argtypes = [P(u64)]
     _lib = L
     return L
 

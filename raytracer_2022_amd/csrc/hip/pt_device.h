@@ -61,6 +61,7 @@ struct SceneDev {
     uint32_t n_nodes;                  // records in `nodes`
     uint32_t n_xforms, n_media;        // records in `xforms`, `media_dev`
     uint32_t n_spheres, n_moving_spheres;
+    uint32_t n_rects;                  // (0 with FEAT 0: every primitive is a sphere — the scenes that take the single-precision slab test)
 };
 
 // Counter block in HBM (same order as rt_stats' integer fields).
@@ -251,6 +252,9 @@ hipError_t launch_math_probe(int op, const double *a, const double *b, double *o
 hipError_t launch_rng_probe(uint64_t state, int mode, double lo, double hi, uint64_t bound, uint64_t *out, uint64_t n, hipStream_t stream);
 // Which traversal variant the wavefront engine launches for a scene without counters: {threads per workgroup, stack entries, nodes kept in LDS}.
 void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features, uint32_t out[4]);
+// {fast-path node steps that took the single-precision slab test, those it left undecided, 1 if this build counts (-DRT2022_F32_CENSUS),
+// RT2022_F32_SLABS of the build, verdicts that differed from the double-precision test's (census builds make both)}; clears the counters.
+hipError_t f32_slab_census(unsigned long long out[5]);
 // Occupancy-derived persistent grid size for the given variant.
 int render_grid_blocks(uint32_t stack_need, bool counters);
 

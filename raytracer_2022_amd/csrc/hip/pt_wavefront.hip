@@ -63,6 +63,11 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // (records whose size is 8 mod 16)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RT2022_F32_SLABS
+#define RT2022_F32_SLABS 1             // node table in LDS: single-precision slab test with a double-precision second opinion (wf_trace, t_slabs32):
+                                       // 1 the all-in-LDS instance of sphere-only scenes, 2 every instance that holds the whole table (A/B, census), 0 none
+#endif
 template <class T>
 RT_DEV void t_pin(T &v) { asm volatile("" : "+v"(v)); }
 // The wave's vote as the hardware gives it (a v_cmp into an SGPR pair); HIP's __ballot materialises the predicate as 0 / 1 first.
@@ -839,6 +844,10 @@ struct TLane {
     // (node table in LDS, RT2022_SIGNED_SLABS) byte addresses, within the table's record 0, of the box coordinate the ray meets
     // first / last on each axis: bmin / bmax by the sign of 1/d — set wherever inv is (t_slabs)
     uint32_t near_at[3], far_at[3];
+    // (single-precision slab test, RT2022_F32_SLABS) per axis {(float)(1/d), (float)(-o/d)} — one operand pair of the packed
+    // multiply-add that gives the axis' two slab distances — and the ray's share of the test's error bound; set with near_at
+    f32x2 p32[3];
+    float e_ray;
     uint32_t slot;
     uint32_t entry;        // where on the ray list the slot was found (its kind goes back to the same place)
     uint32_t steps;        // node steps of this ray
@@ -850,6 +859,7 @@ struct TLane {
     //   kPlain     the fast node step applies to this ray (see there)
     //   kHasRay    the lane carries a ray
     //   kSubFound  the medium sub-query in progress has found a boundary hit
+    //   kNeed64    the single-precision slab test could not decide the node step at hand: the voted node arm takes it in double precision
     uint32_t flags;
 };
 
@@ -860,7 +870,7 @@ struct TStack {
     RT_DEV uint32_t pop(TLane &L) { if (L.sp > 0) { L.sp--; return col[L.sp * WG]; } return REF_EMPTY; }
 };
 
-constexpr uint32_t kPlain = 1u, kHasRay = 2u, kSubFound = 4u;
+constexpr uint32_t kPlain = 1u, kHasRay = 2u, kSubFound = 4u, kNeed64 = 8u;
 RT_DEV void t_flag(TLane &L, uint32_t bit, bool on) { L.flags = on ? (L.flags | bit) : (L.flags & ~bit); asm volatile("" : "+v"(L.flags)); }
 RT_DEV bool t_finite(double x) { return (rtm::d2u(x) & 0x7FF0000000000000ull) != 0x7FF0000000000000ull; }
 // The fast node step applies (see there): every 1/d finite and non-zero, origin finite, boxes plain.
@@ -878,6 +888,46 @@ RT_DEV void t_slabs(TLane &L, uint32_t table_at) {
         L.near_at[i] = table_at + (neg ? 24u : 0u) + 8u * (uint32_t)i;          // record: bmin x y z at +0 +8 +16, bmax at +24 +32 +40
         L.far_at[i] = table_at + (neg ? 0u : 24u) + 8u * (uint32_t)i;
     }
+}
+// The single-precision slab test of the node table in LDS (RT2022_F32_SLABS; see the fast path). A node record there is eleven
+// words: per axis {(float)bmin, (float)bmax, (float)bmin} — so that ONE two-word read at `base` or at `base + 4` delivers the
+// pair in the order (first met, last met) for either sign of 1/d — then the left child and the push ref.
+constexpr uint32_t kNode32Words = 11, kNode32Bytes = 4 * kNode32Words;
+// Error bound (u = 2^-24). With b32 = (float)b, i32 = (float)(1/d), n32 = (float)(-o * (1/d)) the kernel computes
+// t32 = fma(b32, i32, n32) where the double-precision step computes T = (b - o) * (1/d), rounded twice. Against the real
+// number R = b/d - o/d (1/d being the f64 value both use):
+//   |b32 i32 - b/d| <= |b/d| (2u + u^2),   |n32 + o/d| <= |o/d| (u + 2^-52),   the fma rounds once: u (1 + u) |t32|,   |T - R| <= 2^-52 |R|,
+// and with |b/d| <= |R| + |o/d|, |R| <= |t32| + error, |o/d| <= |n32| (1 + u):
+//   |t32 - T| <= 3.000001 u (|t32| + |n32|)
+// — an error relative to the VALUE plus a constant of the ray, k = 3.000001 u max |n32|; nothing in it depends on how large the
+// scene's other coordinates are. (A bound from the largest box coordinate instead was tried first: with 0.2-unit spheres on
+// a 2000-unit ground it left a few per cent of the node steps undecided, and the kernel 10 % slower than the double-precision
+// one.) The window's two ends, converted to float, are off by u of their value: the same form. x -> x + c|x| and x -> x - c|x|
+// are increasing, so the max / min of such values is off by at most c |max| + k, and the rounded difference of the two by
+//   (3.000001 u + u) (|tmx32| + |tmn32|) + 6.000002 u max |n32|   <   4.5 u (|tmx32| + |tmn32|) + e_ray,   e_ray = 6.5 u max |n32| + 2e-8
+// (2e-8 for box coordinates below the float normal range, see t_slabs32; the eighths of slack cover the three roundings of the bound's own arithmetic, 3 u each at most).
+// It has to be this tight: a ray that leaves a surface tests the boxes that surface lies on the face of, where the verdict hangs
+// on t_min = 0.001 against a distance of zero — with coordinates in the hundreds the bound is a few 1e-4 of that.
+// Any overflow on the way (1/d beyond f32) makes a value or the bound infinite or NaN: the test then decides nothing and
+// the lane takes the double-precision step.
+constexpr float kF32RelBound = 4.5f * 0x1p-24f, kF32RayBound = 6.5f * 0x1p-24f;
+RT_DEV void t_slabs32(TLane &L, uint32_t table_at) {
+    float e = 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const bool neg = L.inv[i] < 0.0;
+        L.near_at[i] = table_at + 12u * (uint32_t)i + (neg ? 4u : 0u);
+        const float i32 = (float)L.inv[i], n32 = (float)(-(L.cur.o[i] * L.inv[i]));
+        L.p32[i] = (f32x2){i32, n32};
+        e = __builtin_fmaxf(e, __builtin_fabsf(n32));           // (n32 is no NaN for a plain ray — finite origin, finite non-zero 1/d — and only those take the test)
+        // The analysis above takes i32 to be 1/d within u, and a float box coordinate within u of the double — or within 1.2e-38
+        // of it, for a coordinate below the normal range: 1/d between 1e-30 and 1e30 makes the first true and keeps what the
+        // second adds below the 2e-8 of e_ray; directions outside that range leave every step to the double-precision test.
+        const float ai = __builtin_fabsf(i32);
+        ok = ok && ai >= 1e-30f && ai <= 1e30f;
+    }
+    L.e_ray = ok ? __builtin_fmaf(e, kF32RayBound, 2e-8f) : __builtin_inff();
 }
 RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
@@ -976,6 +1026,11 @@ RT_DEV void t_settle(const SceneDev &s, TLane &L, TStack<STACK, WG> &st, double 
 
 } // namespace
 
+// Census of the single-precision slab test (diagnostic build -DRT2022_F32_CENSUS only): node steps of the fast path that took
+// it, how many of them it left to the double-precision test, and how many of its verdicts differed from that test's (the census
+// build makes both): read and cleared by f32_slab_census (rt_debug_f32_slabs).
+__device__ unsigned long long g_f32_census[3];
+
 // Phase clock of the traversal kernel (diagnostic build -DRT2022_TRACE_PROBE only): every wave adds the shader-clock
 // ticks it spent in each phase of the scheduler — [0] node fast path, [1] vote, [2..9] the voted arms by label (node,
 // sphere, rect, box, medium, misc, ctx, done), [10] the rest — to pool.dbg[96 + phase]; printed after the render.
@@ -1028,9 +1083,19 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // (The deeper-stack variants have no LDS to spare at four workgroups per CU: they fetch it from the pool again.)
     constexpr bool kStash = (FEAT & kFeatMovers) != 0 && STACK <= kStackSmall && CACHE == 0;
     __shared__ double wray_lds[kStash ? 6 * WG : 6];
-    // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node.
-    __shared__ f64x2 nc_box[CACHE > 0 ? 3 * CACHE : 1];
-    __shared__ u32x2 nc_ref[CACHE > 0 ? CACHE : 1];
+    // Node cache (CACHE > 0): boxes as three 16-byte words per node, child refs as one 8-byte word per node — or (kF32: the
+    // all-in-LDS instance of sphere-only scenes) the single-precision records of t_slabs32, 44 bytes per node; the double-precision
+    // boxes then stay in L2 for the few node steps the single-precision test cannot decide. Why sphere-only scenes: what the
+    // float test cannot decide is a ray leaving a surface against a box that surface lies on the face of (the verdict hangs on
+    // t_min = 0.001 against a distance of zero); a sphere touches its box in six points, a rect or a box lies in its faces:
+    // one node step in 96 000 on the random spheres, one in 194 on the book-2 final scene, one in 27 in the Cornell box
+    // (tools/f32_census.py) — measured, the random spheres' traversal kernel 6-7 % faster, the final scene's 1 % and the
+    // Cornell box's 6 % slower, whether the undecided lanes fetch the double-precision box on the spot or hand the step to the
+    // voted arm (profiles/r3q_ab_f32_slabs.log).
+    constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
+    __shared__ f64x2 nc_box[CACHE > 0 && !kF32 ? 3 * CACHE : 1];
+    __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 ? CACHE : 1];
+    __shared__ uint32_t nc32[kF32 ? kNode32Words * CACHE : 1];
     // ... and, in every variant (384 bytes), the first records of the two small tables the arms go to most: movers (32 B
     // each) and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
 #ifndef RT2022_SMALL_TABLES_EVERYWHERE
@@ -1057,8 +1122,18 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
             const u32x4 rw = reinterpret_cast<const u32x4 *>(np)[3];          // {left, right, push ref, -}: see rt_scene_create
             const u32x2 rr = {rw.x, rw.z};
-            nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
-            nc_ref[i] = rr;
+            if (kF32) {
+                const float lo[3] = {(float)b0.x, (float)b0.y, (float)b1.x}, hi[3] = {(float)b1.y, (float)b2.x, (float)b2.y};
+                uint32_t *rec = nc32 + kNode32Words * i;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    rec[3 * a] = __float_as_uint(lo[a]); rec[3 * a + 1] = __float_as_uint(hi[a]); rec[3 * a + 2] = __float_as_uint(lo[a]);
+                }
+                rec[9] = rr.x; rec[10] = rr.y;
+            } else {
+                nc_box[3 * i] = b0; nc_box[3 * i + 1] = b1; nc_box[3 * i + 2] = b2;
+                nc_ref[i] = rr;
+            }
         }
         if (PRIMS) {
             for (uint32_t i = tid; i < s.n_spheres && i < (uint32_t)kPrimSpheres; i += (uint32_t)WG) {
@@ -1124,6 +1199,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     uint32_t touch_word = 0;
 #endif
     TP_DECL;
+#ifdef RT2022_F32_CENSUS
+    unsigned f32_steps = 0, f32_undecided = 0, f32_wrong = 0;
+#endif
     TLane L;
     L.flags = 0; L.op = OP_SHADE; L.top = REF_EMPTY; L.sp = 0; L.slot = 0; L.entry = 0; L.steps = 0;
     L.closest = rtm::F64_MAX; L.a_len = 0.0; L.tm = 0.0;
@@ -1149,14 +1227,19 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
 #ifndef RT2022_SIGNED_SLABS
 #define RT2022_SIGNED_SLABS 1          // node table in LDS: the near / far box coordinate of each axis fetched by the sign of 1/d (no min / max per axis)
 #endif
-    constexpr bool kSlabs = RT2022_SIGNED_SLABS && CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc);      // (a partial table mixes both sources in one wave; the triangle kernels have no six registers to spare)
+    constexpr bool kSlabs = RT2022_SIGNED_SLABS && CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc) && !kF32;      // (a partial table mixes both sources in one wave; the triangle kernels have no six registers to spare)
     typedef const __attribute__((address_space(3))) f64x2 *LdsBoxPtr;
     typedef const __attribute__((address_space(3))) u32x2 *LdsRefPtr;
     LdsBoxPtr ncb = (LdsBoxPtr)nc_box;
     LdsRefPtr ncr = (LdsRefPtr)nc_ref;
     if (CACHE > 0) asm volatile("" : "+v"(ncb), "+v"(ncr));
-    const uint32_t table_at = (uint32_t)(uintptr_t)ncb;              // (LDS byte address of node record 0's box)
+    uint32_t table32_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)nc32;
+    if (kF32) asm volatile("" : "+v"(table32_at));
+    const uint32_t table_at = kF32 ? table32_at : (uint32_t)(uintptr_t)ncb;              // (LDS byte address of node record 0's box)
     L.near_at[0] = L.near_at[1] = L.near_at[2] = L.far_at[0] = L.far_at[1] = L.far_at[2] = table_at;
+    L.p32[0] = L.p32[1] = L.p32[2] = (f32x2){0.0f, 0.0f}; L.e_ray = __builtin_inff();
+    uint32_t refs32_at = table32_at + 36u;                             // (kF32: the child refs of record 0)
+    if (kF32) asm volatile("" : "+v"(refs32_at));
 
     for (;;) {
         // Fast path: keep stepping nodes while enough lanes want to — nn >= the quorum. Below the quorum the vote
@@ -1168,7 +1251,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         // The loop itself is a plain divergent loop over the node lanes — a lane that leaves the node state drops out
         // of it, and all that are left go together when their count falls below the threshold.
         {
-            bool isn = (L.op | (~L.flags & kPlain)) == 0u;             // a node step (OP_NODE is label 0) of a plain ray: one compare, one vote
+            // a node step (OP_NODE is label 0) of a plain ray — and not one the single-precision test has handed on: one compare, one vote
+            bool isn = kF32 ? (L.op | ((L.flags ^ kPlain) & (kPlain | kNeed64))) == 0u : (L.op | (~L.flags & kPlain)) == 0u;
             int nn = __popcll(wballot(isn));
             const int pending = __popcll(wballot(L.op != OP_IDLE));
             const int tail_threshold = tail_factor * pending / (tail_factor + 1) + 1;
@@ -1177,6 +1261,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             double tlo_c = L.t_lo, thi_c = t_hi(L);
             asm volatile("" : "+v"(tlo_c), "+v"(thi_c));              // (in vector registers, once per entry)
             const bool entered = isn && nn >= threshold;
+            // (kF32) the window's ends in single precision and the error bound of this entry: the ray's share plus what the
+            // two conversions can be off by (an infinite end converts exactly)
+            float tlo32 = 0.0f, thi32 = 0.0f;
+            if (kF32 && entered) {
+                tlo32 = (float)tlo_c; thi32 = (float)thi_c;
+                asm volatile("" : "+v"(tlo32), "+v"(thi32));
+            }
             if (entered) do {
                 if (STATS) { const unsigned long long am = wballot(true); if ((int)lane == __ffsll((long long)am) - 1) { census_rounds[8]++; census_lanes[8] += (unsigned)nn; } }
                 {
@@ -1191,12 +1282,61 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 //
                 // Straight-line on purpose: the node's 64 bytes and the stack entry below the top are
                 // requested together, before the arithmetic — no load waits for the outcome of the test.
-                cnt.node();
-                L.steps++;
                 const uint32_t nidx = RT_REF_INDEX(L.top);
                 const int below_sp = L.sp > 0 ? L.sp - 1 : 0;
                 double bmin[3], bmax[3];
                 uint32_t left, right, below;
+                bool hit, undecided = false;
+                if (kF32) {
+                    // Single-precision slab test with a double-precision second opinion (r3). The node's box is held as floats
+                    // (t_slabs32: one two-word LDS read per axis delivers the coordinates the ray meets first and last), the two
+                    // slab distances of an axis are ONE packed multiply-add, max3 / min3 fold the axes: ten vector instructions
+                    // where the double-precision test needs nineteen. Its verdict is taken only where it cannot differ from the
+                    // double-precision one: |tmx - tmn| above the error bound of t_slabs32; a lane it leaves undecided (one node step
+                    // in 200 on the book-2 final scene, one in 70 000 on the random spheres: tools/f32_census.py) hands the step to the
+                    // voted node arm, which fetches the double-precision record. Same decisions, bit for bit.
+                    uint32_t a0, a1, a2, ar;
+                    asm("v_mad_u32_u24 %0, %1, 44, %2" : "=v"(a0) : "v"(L.top), "v"(L.near_at[0]));
+                    asm("v_mad_u32_u24 %0, %1, 44, %2" : "=v"(a1) : "v"(L.top), "v"(L.near_at[1]));
+                    asm("v_mad_u32_u24 %0, %1, 44, %2" : "=v"(a2) : "v"(L.top), "v"(L.near_at[2]));
+                    asm("v_mad_u32_u24 %0, %1, 44, %2" : "=v"(ar) : "v"(L.top), "v"(refs32_at));
+                    static_assert(kNode32Bytes == 44, "the multiply-adds above carry the record size");
+                    const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
+                    f32x2 bx, by, bz, tx, ty, tz;
+                    u32x2 cr;
+                    asm volatile("ds_read2_b32 %0, %5 offset1:1\n\tds_read2_b32 %1, %6 offset1:1\n\tds_read2_b32 %2, %7 offset1:1\n\t"
+                                 "ds_read2_b32 %3, %8 offset1:1\n\tds_read_b32 %4, %9\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(bx), "=&v"(by), "=&v"(bz), "=&v"(cr), "=&v"(below) : "v"(a0), "v"(a1), "v"(a2), "v"(ar), "v"(below_at) : "memory");
+                    // {t first, t last} = {b first, b last} * (1/d) + (-o/d): low halves of both results take the pair's low word, the addend its high word
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tx) : "v"(bx), "v"(L.p32[0]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(ty) : "v"(by), "v"(L.p32[1]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "v"(bz), "v"(L.p32[2]));
+                    float tmn32, tmx32;
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmn32) : "v"(tx.x), "v"(ty.x), "v"(tz.x));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmx32) : "v"(tx.y), "v"(ty.y), "v"(tz.y));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(tmn32) : "v"(tmn32), "v"(tlo32));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(tmx32) : "v"(tmx32), "v"(thi32));
+                    const float gap = tmx32 - tmn32;
+                    hit = gap > 0.0f;
+                    const float e_tot = __builtin_fmaf(__builtin_fabsf(tmx32) + __builtin_fabsf(tmn32), kF32RelBound, L.e_ray);
+                    undecided = !(__builtin_fabsf(gap) > e_tot);                   // (a NaN anywhere lands here too)
+#ifdef RT2022_F32_CENSUS
+                    f32_steps++; if (undecided) f32_undecided++;
+                    if (!undecided) {                                      // (the census build checks every verdict it takes against the double-precision test)
+                        const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + nidx);
+                        const f64x2 n0 = np[0], n1 = np[1], n2 = np[2];
+                        const double lo3[3] = {n0.x, n0.y, n1.x}, hi3[3] = {n1.y, n2.x, n2.y};
+                        double tmn = tlo_c, tmx = thi_c;
+                        for (int i = 0; i < 3; i++) {
+                            const double t0 = (lo3[i] - L.cur.o[i]) * L.inv[i], t1 = (hi3[i] - L.cur.o[i]) * L.inv[i];
+                            tmn = __builtin_fmax(tmn, __builtin_fmin(t0, t1));
+                            tmx = __builtin_fmin(tmx, __builtin_fmax(t0, t1));
+                        }
+                        if (hit != !(tmx <= tmn)) f32_wrong++;
+                    }
+#endif
+                    left = cr.x; right = cr.y;
+                } else {
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                     // (LDS addresses are 32 bits and a table index is far below 2^24: one v_mad_u32_u24 instead of a 64-bit multiply-add)
                     // (the 24-bit multiply-add takes the low 24 bits of the ref: its index, un-masked)
@@ -1248,13 +1388,23 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     asm("v_max_f64 %0, %1, %2" : "=v"(tmn) : "v"(i == 0 ? tlo_c : tmn), "v"(lo));
                     asm("v_min_f64 %0, %1, %2" : "=v"(tmx) : "v"(i == 0 ? thi_c : tmx), "v"(hi));
                 }
-                const bool hit = !(tmx <= tmn);
+                hit = !(tmx <= tmn);
+                }
                 // A span-1 node holds the same object twice (bvh/mod.rs:44-47). Testing a plain
                 // primitive a second time against t_max = its own t finds the same hit again, so
                 // only the count of tests is kept; anything that can draw from the RNG or carry
                 // movers (media, movers, nodes, lists) is really visited twice. rt_scene_create has
                 // worked that out per node: `right` here is the node's PUSH REF — its right child, or
                 // REF_EMPTY where the twin needs no second visit (r3: one compare instead of five).
+                if (kF32 && undecided) {
+                    // Mostly a ray leaving a surface against a box that surface lies on the face of: the verdict hangs on t_min = 0.001
+                    // against a distance of zero, which floats of the scene's size cannot tell apart. The lane keeps its node and leaves
+                    // the loop; the voted node arm takes the step on the double-precision record (no lane here waits for that fetch).
+                    L.flags |= kNeed64;
+                    isn = false;
+                } else {
+                cnt.node();
+                L.steps++;
                 const bool twin = right == ref_empty;
                 const bool push = hit && !twin && L.sp < STACK;
                 if (push) st.col[L.sp * WG] = right;
@@ -1265,6 +1415,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 // (a node ref is kind 0 without the FlipFace bit — rt_scene_create refuses a flipped node — so "another node step"
                 // is one compare; the label of whatever else came up is looked up once, when the lane leaves the loop)
                 isn = next < (1u << RT_REF_KIND_SHIFT);
+                }
                 }
                 nn = __popcll(wballot(isn));
             } while (isn && nn >= threshold);
@@ -1298,7 +1449,31 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             const uint32_t nidx = RT_REF_INDEX(L.top);
             f64x2 n0, n1, n2;
             u32x4 n3;
-            if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
+            bool decided = false, miss = false;
+            if (kF32) {
+                // (the single-precision test of the fast path for the plain rays that come through here — a node step below the
+                // quorum; everything else, and what it leaves undecided, takes the literal test on the double-precision record)
+                const uint32_t *rec = nc32 + kNode32Words * nidx;
+                n3 = (u32x4){rec[9], 0u, rec[10], 0u};
+                if ((L.flags & (kPlain | kNeed64)) == kPlain) {
+                    const float tlo32 = (float)L.t_lo, thi32 = (float)t_hi(L);
+                    float tmn32 = tlo32, tmx32 = thi32;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const bool neg = L.inv[i] < 0.0;
+                        const float lo = __uint_as_float(rec[3 * i]), hi = __uint_as_float(rec[3 * i + 1]);
+                        const float t0 = __builtin_fmaf(neg ? hi : lo, L.p32[i].x, L.p32[i].y), t1 = __builtin_fmaf(neg ? lo : hi, L.p32[i].x, L.p32[i].y);
+                        tmn32 = __builtin_fmaxf(tmn32, t0); tmx32 = __builtin_fminf(tmx32, t1);
+                    }
+                    const float gap = tmx32 - tmn32;
+                    const float e_tot = __builtin_fmaf(__builtin_fabsf(tmx32) + __builtin_fabsf(tmn32), kF32RelBound, L.e_ray);
+                    decided = __builtin_fabsf(gap) > e_tot;
+                    miss = decided && !(gap > 0.0f);
+                }
+            }
+            if (kF32 && decided) {
+                n0 = n1 = n2 = (f64x2){0.0, 0.0};
+            } else if (CACHE > 0 && !kF32 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const u32x2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, 0u, cr.y, 0u};
@@ -1310,7 +1485,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             t_pin(n0); t_pin(n1); t_pin(n2); t_pin(n3);
             const double bmin[3] = {n0.x, n0.y, n1.x}, bmax[3] = {n1.y, n2.x, n2.y};
             double tmn = L.t_lo, tmx = t_hi(L);
-            bool miss = false;
+            if (!(kF32 && decided)) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 double inv_d = L.inv[i];
@@ -1321,6 +1496,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 tmx = t1 < tmx ? t1 : tmx;
                 miss = miss || (tmx <= tmn);
             }
+            }
+            if (kF32) L.flags &= ~kNeed64;
             if (!miss) {
                 const uint32_t left = n3.x, push_ref = n3.z;           // (push ref: see the fast path)
                 if (push_ref == REF_EMPTY) cnt.prim(RT_REF_KIND(left));
@@ -1557,7 +1734,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     L.a_len = L.cur.d.length_sqr();
                 }
                 t_flags(L, boxes_plain);
-                if (kSlabs) t_slabs(L, table_at);
+                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
                 T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -1585,7 +1762,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                         L.cur.o = L.cur.o / p0;
                     }
                     t_flags(L, boxes_plain);
-                    if (kSlabs) t_slabs(L, table_at);
+                    if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
                     L.ctx.push(L.top);
                     st.push(L, REF_POPCTX);
                     L.top = x0.y;
@@ -1670,7 +1847,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
-                if (kSlabs) t_slabs(L, table_at);
+                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
                 if (FEAT & kFeatMovers) L.stash_level = 0xFFFFFFFFu;
                 if (kStash) {                                         // what leaving a mover goes back to (OP_CTX)
                     wray[0 * WG] = wr.orig.x; wray[1 * WG] = wr.orig.y; wray[2 * WG] = wr.orig.z;
@@ -1692,6 +1869,11 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         TP_MARK(2 + best);
     }
     TP_FLUSH();
+#ifdef RT2022_F32_CENSUS
+    if (f32_steps) atomicAdd(&g_f32_census[0], (unsigned long long)f32_steps);
+    if (f32_undecided) atomicAdd(&g_f32_census[1], (unsigned long long)f32_undecided);
+    if (f32_wrong) atomicAdd(&g_f32_census[2], (unsigned long long)f32_wrong);
+#endif
     if (probe && lane == 0) {
         unsigned long long t_end = wall_clock64();
         atomicMin(&pool.dbg[0], t_start);
@@ -1803,7 +1985,7 @@ static int node_cache_mode(const SceneDev &scene, uint32_t stack_need, uint32_t 
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
     static const bool prims = [] { const char *e = getenv("RT2022_PRIM_TABLES"); return !(e && e[0] == '0'); }();
     if (!enabled || (tuning & (1u << 28)) || stack_need > (uint32_t)kStackTiny) return 0;
-    if (prims && features == 0 && scene.n_nodes <= (uint32_t)kPrimNodes && scene.n_spheres <= (uint32_t)kPrimSpheres &&
+    if (prims && features == 0 && scene.n_rects == 0 && scene.n_nodes <= (uint32_t)kPrimNodes && scene.n_spheres <= (uint32_t)kPrimSpheres &&
         scene.n_moving_spheres <= (uint32_t)kPrimMoving) return 3;
     return scene.n_nodes <= (uint32_t)kNodeCache ? 1 : 2;
 }
@@ -2046,6 +2228,22 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
     }
     if (out_iterations) *out_iterations = iterations;
     return hipSuccess;
+}
+
+hipError_t f32_slab_census(unsigned long long out[5]) {
+    unsigned long long c[3] = {0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(c, HIP_SYMBOL(g_f32_census), sizeof(c));
+    if (e != hipSuccess) return e;
+    const unsigned long long zero[3] = {0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_f32_census), zero, sizeof(zero));
+    out[0] = c[0]; out[1] = c[1]; out[4] = c[2];
+#ifdef RT2022_F32_CENSUS
+    out[2] = 1;
+#else
+    out[2] = 0;
+#endif
+    out[3] = RT2022_F32_SLABS;
+    return e;
 }
 
 void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features, uint32_t out[4]) {

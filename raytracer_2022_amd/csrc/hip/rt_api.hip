@@ -3,7 +3,9 @@
 // HIP device and reports RT_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -766,6 +768,7 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
             s.n_media = desc->n_media;
             s.n_spheres = desc->n_spheres;
             s.n_moving_spheres = desc->n_moving_spheres;
+            s.n_rects = desc->n_rects;
             sc->stack_need = (uint32_t)need;
             sc->general_boundaries = v.general_boundaries;
             sc->boxes_plain = v.boxes_plain();
@@ -1234,6 +1237,16 @@ int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, u
         if (stack_entries) *stack_entries = v[1];
         if (nodes_in_lds) *nodes_in_lds = v[2];
         if (spheres_in_lds) *spheres_in_lds = v[3];
+        return RT_OK;
+    });
+}
+
+int rt_debug_f32_slabs(uint64_t out[5]) {
+    return guarded([&]() -> int {
+        RT_REQUIRE(out, RT_ERR_INVALID, "rt_debug_f32_slabs: null output");
+        unsigned long long v[5] = {0, 0, 0, 0, 0};
+        RT_HIP(f32_slab_census(v));
+        for (int i = 0; i < 5; i++) out[i] = v[i];
         return RT_OK;
     });
 }

@@ -309,6 +309,72 @@ def test_node_step_variants(rt, O):
     assert st_ref.node_visits > 0
 
 
+def test_single_precision_slab_test_on_hostile_spheres(rt, O):
+    """The traversal kernel of sphere-only scenes tests node boxes in single precision and hands a step to the double-precision
+    test wherever the two could differ (wf_trace, t_slabs32: the error bound is derived there). Scenes built to sit on that
+    edge — box faces through the ray origins, coordinates where a float's spacing exceeds the sphere, a 1e-6 sphere on a 1e6
+    one, directions whose reciprocal leaves the float range — against the oracle, bit for bit, pixels and counters."""
+    out5 = (C.c_uint64 * 5)()
+    F.check(F.lib().rt_debug_f32_slabs(out5))
+    assert out5[3] == 1, "this library is built without the single-precision slab test of the sphere-only kernel"
+
+    def spheres_scene(items):
+        b = rt.DescBuilder()
+        mats = [b.lambertian((0.7, 0.6, 0.5)), b.metal((0.8, 0.8, 0.9), 0.0), b.dielectric(1.5)]
+        leaves = []
+        for i, (c, r) in enumerate(items):
+            sp = b.sphere(c, r, mats[i % 3])
+            leaves.append((sp, tuple(x - abs(r) for x in c), tuple(x + abs(r) for x in c)))
+
+        def build(nodes):
+            if len(nodes) == 1:
+                r, lo, hi = nodes[0]
+                return b.node(lo, hi, r, r), lo, hi
+            h = len(nodes) // 2
+            l, llo, lhi = build(nodes[:h])
+            r, rlo, rhi = build(nodes[h:])
+            lo = tuple(min(a, c_) for a, c_ in zip(llo, rlo)); hi = tuple(max(a, c_) for a, c_ in zip(lhi, rhi))
+            return b.node(lo, hi, l, r), lo, hi
+        root, _, _ = build(leaves)
+        b.set_root(root)
+        return b.desc()
+
+    W, H, spp = 48, 32, 8
+    rows = np.arange(H, dtype=np.uint32)
+    p = rt.make_params(W, H, spp, 16, (0.6, 0.7, 0.9), seed=9)
+    rng = np.random.default_rng(4)
+    # unit spheres on integer centres seen from an integer point: box faces pass through ray origins (hits restart ON the spheres' boxes' faces at the poles)
+    lattice = [((float(x), float(y), float(z)), 1.0) for x in (-2, 0, 2) for y in (-2, 0, 2) for z in (-8, -6)]
+    # a cluster 1e7 away: a float there is spaced 1 apart, the spheres are 0.5 across
+    far = [((1e7 + float(dx), 1e7 + float(dy), -1e7 + float(dz)), 0.25) for dx, dy, dz in rng.uniform(-3, 3, size=(14, 3))]
+    # a 1e-6 sphere resting on a 1e6 one, and neighbours of ordinary size
+    scales = [((0.0, -1e6, -5.0), 1e6), ((0.0, 1e-6, -5.0), 1e-6), ((0.5, 0.5, -5.0), 0.5), ((-0.7, 0.3, -4.0), 0.3)]
+    cams = {
+        "lattice": rt.camera_new((0.0, 0.0, 4.0), (0.0, 0.0, -7.0), (0, 1, 0), 40.0, W / H, 0.0, 10.0, 0.0, 1.0),
+        "far": rt.camera_new((1e7 + 0.5, 1e7 + 1.0, -1e7 + 12.0), (1e7, 1e7, -1e7), (0, 1, 0), 40.0, W / H, 0.0, 10.0, 0.0, 1.0),
+        "scales": rt.camera_new((0.0, 1e-5, -4.99), (0.0, 1e-6, -5.0), (0, 1, 0), 30.0, W / H, 0.0, 1.0, 0.0, 1.0),
+    }
+    # directions with one component of 1e-42 (1/d = 1e42: outside the float range, finite in double): every step of such a ray is the double-precision test's
+    thin = F.rt_camera.from_buffer_copy(cams["lattice"])
+    thin.origin = (C.c_double * 3)(0.25, 0.125, 4.0)
+    thin.lower_left_corner = (C.c_double * 3)(0.25 - 2.0, 0.125 + 1e-42, 3.0)
+    thin.horizontal = (C.c_double * 3)(4.0, 0.0, 0.0)
+    thin.vertical = (C.c_double * 3)(0.0, 0.0, 0.0)
+    thin.lens_radius = 0.0
+    for label, items, cam in (("lattice", lattice, cams["lattice"]), ("far cluster", far, cams["far"]), ("scales", scales, cams["scales"]),
+                              ("1/d beyond float", lattice, thin)):
+        d = spheres_scene(items)
+        ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=4, want_stats=True)
+        dev = rt.DeviceScene(d)
+        v = dev.trace_variant()
+        assert v["spheres_in_lds"] and v["nodes_in_lds"] == d.n_nodes, (label, v)     # (the instance with the single-precision test)
+        out, st = dev.render(cam, p, rows, want_stats=True)
+        assert st.as_dict() == st_ref.as_dict(), label
+        assert np.array_equal(bits(out), bits(ref)), label
+        assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), label       # (the timed kernel: the one that holds the test)
+        assert st_ref.node_visits > 0 and st_ref.rays > W * H * spp, label
+
+
 def test_scheduling_knobs_never_change_results(rt, O):
     """Segments per traversal workgroup, stream groups, pacing, the timing probe: speed only (rt2022_debug.h)."""
     def word(q=18, reps=1, tail=2, segs=4, shift=2, groups=1, extra=0):
