@@ -56,6 +56,23 @@ def lib_libm():
     return _lib_libm
 
 
+OWN_LIB_PATH = os.path.join(_HERE, "librt_oracle_own.so")
+_lib_own = None
+
+
+def lib_own():
+    """The -DRTO_OWN_MATH build: rt_oracle.cpp against oracle/rto_math.h (the oracle's own vectors, RNG conversions and casts) and
+    the platform libm — no arithmetic shared with the product. For tests/test_oracle_own_math.py only."""
+    global _lib_own
+    if _lib_own is not None:
+        return _lib_own
+    if not os.path.exists(OWN_LIB_PATH):
+        build("own")
+    _lib_own = _bind(C.CDLL(OWN_LIB_PATH))
+    assert _lib_own.rto_uses_own_math() == 1 and _lib_own.rto_uses_libm() == 1 and lib().rto_uses_own_math() == 0
+    return _lib_own
+
+
 def _bind(L):
     P, dbl, u64, u32 = C.POINTER, C.c_double, C.c_uint64, C.c_uint32
     L.rt_render_cpu.argtypes = [P(F.rt_scene_desc), P(F.rt_camera), P(F.rt_params), P(dbl), P(F.rt_stats), C.c_int]
@@ -87,6 +104,7 @@ def _bind(L):
     L.rto_path_key.argtypes = [u64, u32, u64, u32]
     L.rto_path_key.restype = u64
     L.rto_uses_libm.restype = C.c_int
+    L.rto_uses_own_math.restype = C.c_int
     L.rto_path_math.argtypes = [C.c_int, dbl, dbl]
     L.rto_path_math.restype = dbl
     return L
@@ -96,9 +114,10 @@ def _d(v):
     return (C.c_double * len(v))(*[float(x) for x in v])
 
 
-def render_cpu(desc, cam, params, row_ids, n_threads=1, want_stats=False, libm=False):
-    """rt_render_cpu → (n_rows, width, 3) float64 sums [, rt_stats]. libm=True: the -DRTO_LIBM build (lib_libm)."""
-    L = lib_libm() if libm else lib()
+def render_cpu(desc, cam, params, row_ids, n_threads=1, want_stats=False, libm=False, own=False):
+    """rt_render_cpu → (n_rows, width, 3) float64 sums [, rt_stats]. libm=True: the -DRTO_LIBM build (lib_libm); own=True: the
+    -DRTO_OWN_MATH build (lib_own)."""
+    L = lib_own() if own else lib_libm() if libm else lib()
     rows = np.ascontiguousarray(row_ids, dtype=np.uint32)
     p = F.rt_params.from_buffer_copy(params)
     p.n_rows = len(rows)

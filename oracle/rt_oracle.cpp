@@ -27,7 +27,17 @@
 #include <vector>
 
 #include "../include/rt2022.h"
+// Vectors, reflect / refract, Onb, the RNG's conversions and the casts: rt_math.h, shared with the device so that HIP == oracle
+// bit for bit — or, -DRTO_OWN_MATH (`make own`), the oracle's own restatement of the same reference lines, sharing nothing with
+// the product (rto_math.h says what that build is for; it takes its transcendentals from the platform libm like -DRTO_LIBM).
+#ifdef RTO_OWN_MATH
+#include "rto_math.h"
+#ifndef RTO_LIBM
+#define RTO_LIBM
+#endif
+#else
 #include "../raytracer_2022_amd/csrc/rt_math.h"
+#endif
 #include "rt_oracle.h"
 
 using rtm::Ray;
@@ -839,6 +849,14 @@ double rto_math(int op, double a, double b) {
 }
 // 1: this library was built with -DRTO_LIBM (the render path's transcendentals are the platform libm's).
 int rto_uses_libm(void) { return om::kLibm; }
+// 1: this library was built with -DRTO_OWN_MATH (oracle/rto_math.h instead of the product's rt_math.h: nothing shared).
+int rto_uses_own_math(void) {
+#ifdef RTO_OWN_MATH
+    return 1;
+#else
+    return 0;
+#endif
+}
 // The transcendentals AS THE RENDER PATH OF THIS BUILD CALLS THEM (rto_math above is always rt_math.h).
 double rto_path_math(int op, double a, double b) {
     switch (op) {

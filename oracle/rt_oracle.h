@@ -40,6 +40,8 @@ int rto_scatter(const rt_scene_desc *scene, uint32_t mat, const double ray_in[7]
 double rto_math(int op, double a, double b);
 /* 1 if this library was built with -DRTO_LIBM (`make libm`: the render path calls the platform libm). */
 int rto_uses_libm(void);
+/* 1 if this library was built with -DRTO_OWN_MATH (`make own`: oracle/rto_math.h instead of the product's rt_math.h). */
+int rto_uses_own_math(void);
 /* The transcendental as the render path of THIS build calls it (rt_math.h, or the platform libm under -DRTO_LIBM). */
 double rto_path_math(int op, double a, double b);
 void rto_math_array(int op, const double *a, const double *b, double *out, uint64_t n);
