@@ -272,6 +272,8 @@ typedef struct rt_params {
 
 #define RT_FLAG_COUNTERS 0x1u         /* fill the counter fields of rt_stats */
 #define RT_FLAG_KERNEL_TIMES 0x2u     /* fill rt_stats.trace_ms / shade_ms (HIP events around every pass of the default engine) */
+#define RT_FLAG_ASYNC 0x4u            /* rt_render_device only: return as soon as the call is accepted; a host thread of the library
+                                         drives the passes, rt_render_wait(scene, stream) joins it (see rt_render_device) */
 
 typedef struct rt_stats {
     uint64_t paths;                               /* camera rays                         */
@@ -323,7 +325,15 @@ int rt_render(rt_scene *scene, const rt_camera *cam, const rt_params *params,
  * is RT_ERR_INVALID, not a silently mis-keyed frame.
  * The scene lives on the HIP device that was current at rt_scene_create; the call
  * makes that device current for its duration and restores the caller's, and
- * `hip_stream`, the row ids and the output must belong to that device. */
+ * `hip_stream`, the row ids and the output must belong to that device.
+ * RT_FLAG_ASYNC (a flag bit older callers never set: the ABI version stays 3): the call validates its arguments, copies `cam` and `params` and returns; the passes are
+ * driven by a host thread of the library (one per call in flight), so the caller's thread is free — to tonemap or gather
+ * the previous frame, or to start a frame on another stream of the same scene, whose passes then fill the chip while
+ * this one's last rays drain. The device buffers (row ids, output) and `stats` stay the caller's until
+ * rt_render_wait(scene, hip_stream), which joins the thread, returns the call's error if it had one (engine errors
+ * surface there, not here) and fills `stats`; the next rt_render_device on the same (scene, stream) and
+ * rt_scene_destroy wait likewise. params->progress_cb, if any, is called on the library's thread. Results are the
+ * synchronous call's, bit for bit. */
 int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                      double *d_out_rgb_sum, void *hip_stream, rt_stats *stats);
 int rt_render_wait(rt_scene *scene, void *hip_stream);

@@ -22,6 +22,7 @@ RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_NOISE, RT_TEX_IMAGE = range(4)
 RT_MAX_XFORM_DEPTH = 4
 RT_FLAG_COUNTERS = 0x1
 RT_FLAG_KERNEL_TIMES = 0x2
+RT_FLAG_ASYNC = 0x4
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_NOMEM = 0, -1, -2, -3, -4
 
 KIND_NAMES = ["node", "sphere", "moving_sphere", "rect", "box", "triangle", "ring", "medium",

@@ -297,6 +297,11 @@ struct Workspace {
     uint32_t *h_rows_max = nullptr;   // ... and the pinned word it is copied to
     unsigned long long *d_limit = nullptr;   // ring mode: RenderArgs::claim_limit
     uint64_t used_partial_bytes = 0;
+    // RT_FLAG_ASYNC: the host thread that drives the passes of the call in flight on this (scene, stream), and what it ended with
+    // (read by rt_render_wait after the join).
+    std::thread async_worker;
+    int async_rc = RT_OK;
+    std::string async_err;
 };
 
 } // namespace
@@ -793,6 +798,8 @@ int rt_scene_destroy(rt_scene *scene) {
     return guarded([&]() -> int {
         if (!scene) return RT_OK;
         DeviceGuard guard(scene->device);
+        for (auto &kv : scene->ws)                    // (asynchronous calls still in flight: let their host threads finish)
+            if (kv.second.async_worker.joinable()) kv.second.async_worker.join();
         (void)hipDeviceSynchronize();                 // (every stream of the scene's device, the group streams included)
         for (auto &kv : scene->ws) {
             Workspace &w = kv.second;
@@ -824,13 +831,52 @@ int rt_scene_destroy(rt_scene *scene) {
     });
 }
 
+// Joins the worker of an RT_FLAG_ASYNC call in flight on (scene, stream), if any; returns what it ended with.
+static int join_async(rt_scene *scene, hipStream_t stream, std::string *err, bool *joined = nullptr) {
+    Workspace &w = workspace_for(scene, stream);
+    if (joined) *joined = w.async_worker.joinable();
+    if (!w.async_worker.joinable()) return RT_OK;
+    w.async_worker.join();
+    const int rc = w.async_rc;
+    if (err) *err = w.async_err;
+    w.async_rc = RT_OK; w.async_err.clear();
+    return rc;
+}
+
 int rt_render_device(rt_scene *scene, const rt_camera *cam, const rt_params *params,
                      double *d_out_rgb_sum, void *hip_stream, rt_stats *stats) {
     return guarded([&]() -> int {
         check_params(scene, cam, params);
         RT_REQUIRE(d_out_rgb_sum || params->n_rows == 0, RT_ERR_INVALID, "rt_render_device: output is null");
         DeviceGuard guard(scene->device);
-        enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, (hipStream_t)hip_stream, stats, true);
+        const hipStream_t stream = (hipStream_t)hip_stream;
+        {   // one call at a time per (scene, stream): an asynchronous one still in flight is finished first
+            std::string err;
+            bool joined = false;
+            const int rc = join_async(scene, stream, &err, &joined);
+            RT_REQUIRE(rc == RT_OK, rc, "rt_render_device: the previous asynchronous call on this stream failed: " + err);
+            if (joined) finish(scene, stream);        // (its rt_stats, as rt_render_wait would have filled them)
+        }
+        if (!(params->flags & RT_FLAG_ASYNC)) {
+            enqueue(scene, cam, params, params->row_ids, d_out_rgb_sum, stream, stats, true);
+            return RT_OK;
+        }
+        // RT_FLAG_ASYNC: the engine drives its passes from a host thread (it polls one word per batch) — here a thread of the
+        // library's own instead of the caller's. The arguments are copied; the device buffers are the caller's until the wait.
+        Workspace &w = workspace_for(scene, stream);
+        const rt_camera cam_copy = *cam;
+        const rt_params params_copy = *params;
+        w.async_rc = RT_OK; w.async_err.clear();
+        w.async_worker = std::thread([scene, cam_copy, params_copy, d_out_rgb_sum, stream, stats, &w]() {
+            try {
+                DeviceGuard worker_guard(scene->device);
+                enqueue(scene, &cam_copy, &params_copy, params_copy.row_ids, d_out_rgb_sum, stream, stats, true);
+            } catch (const Fail &e) {
+                w.async_rc = e.code; w.async_err = e.msg;
+            } catch (const std::exception &e) {
+                w.async_rc = RT_ERR_INVALID; w.async_err = e.what();
+            }
+        });
         return RT_OK;
     });
 }
@@ -839,6 +885,9 @@ int rt_render_wait(rt_scene *scene, void *hip_stream) {
     return guarded([&]() -> int {
         RT_REQUIRE(scene, RT_ERR_INVALID, "rt_render_wait: null scene");
         DeviceGuard guard(scene->device);
+        std::string err;
+        const int rc = join_async(scene, (hipStream_t)hip_stream, &err);
+        RT_REQUIRE(rc == RT_OK, rc, err);
         finish(scene, (hipStream_t)hip_stream);
         return RT_OK;
     });

@@ -65,11 +65,14 @@ class DeviceScene:
         F.check(F.lib().rt_render(self._h, C.byref(cam), C.byref(p), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
         return (out, st) if want_stats else out
 
-    def render_device(self, cam, params, d_row_ids_ptr, n_rows, d_out_ptr, stream_ptr=None, stats=None):
-        """rt_render_device: device pointers in, enqueue on `stream_ptr` (hipStream_t as int)."""
+    def render_device(self, cam, params, d_row_ids_ptr, n_rows, d_out_ptr, stream_ptr=None, stats=None, asynchronous=False):
+        """rt_render_device: device pointers in, enqueue on `stream_ptr` (hipStream_t as int). asynchronous=True sets
+        RT_FLAG_ASYNC: the call returns at once, a host thread of the library drives the passes, wait() joins it."""
         p = F.rt_params.from_buffer_copy(params)
         p.n_rows = n_rows
         p.row_ids = d_row_ids_ptr
+        if asynchronous:
+            p.flags |= F.RT_FLAG_ASYNC
         F.check(F.lib().rt_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_out_ptr),
                                          C.c_void_p(stream_ptr or 0), C.byref(stats) if stats is not None else None))
 

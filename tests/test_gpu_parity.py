@@ -510,6 +510,51 @@ def test_device_buffers_and_tonemap(rt, O):
     assert st.ms > 0
 
 
+def test_asynchronous_calls_on_two_streams(rt, O):
+    """RT_FLAG_ASYNC: rt_render_device returns at once and a host thread of the library drives the passes; two frames in flight
+    on two streams of ONE scene (each with its own pool), a third queued behind the first, all equal to the oracle bit for bit;
+    an engine-side error (a row id out of range, found by the device-side check) surfaces at rt_render_wait."""
+    import torch
+    s = rt.HostScene("cornell_smoke", seed=2022)
+    W, H, spp = 48, 40, 4
+    cam, bg = s.default_view(W / H)
+    rows = rt.shuffled_rows(H, 3)
+    dev = rt.DeviceScene(s.desc)
+    d_rows = torch.from_numpy(rows.view(np.int32)).cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    seeds = (11, 12, 13)
+    outs = [torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda") for _ in seeds]
+    stats = [F.rt_stats() for _ in seeds]
+    params = [rt.make_params(W, H, spp, 50, bg, seed=sd, spp_chunk=1) for sd in seeds]
+    torch.cuda.synchronize()
+    for p in params:
+        p.flags |= F.RT_FLAG_COUNTERS
+    dev.render_device(cam, params[0], d_rows.data_ptr(), H, outs[0].data_ptr(), streams[0].cuda_stream, stats[0], asynchronous=True)
+    dev.render_device(cam, params[1], d_rows.data_ptr(), H, outs[1].data_ptr(), streams[1].cuda_stream, stats[1], asynchronous=True)
+    # a second call on a stream that still has one in flight waits for it first (one call at a time per scene and stream)
+    dev.render_device(cam, params[2], d_rows.data_ptr(), H, outs[2].data_ptr(), streams[0].cuda_stream, stats[2], asynchronous=True)
+    dev.wait(streams[1].cuda_stream)
+    dev.wait(streams[0].cuda_stream)
+    for i, sd in enumerate(seeds):
+        ref, st_ref = O.render_cpu(s.desc, cam, params[i], rows, n_threads=4, want_stats=True)
+        assert np.array_equal(bits(outs[i].cpu().numpy()), bits(ref)), sd
+        assert stats[i].as_dict() == st_ref.as_dict(), sd         # (the first call's were filled when the third call's start waited for it)
+    # the synchronous form still works on the same workspace, and gives the same bits
+    again = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
+    dev.render_device(cam, params[1], d_rows.data_ptr(), H, again.data_ptr(), streams[1].cuda_stream, None)
+    dev.wait(streams[1].cuda_stream)
+    assert np.array_equal(bits(again.cpu().numpy()), bits(outs[1].cpu().numpy()))
+    # an error found by the engine's thread is reported by the wait
+    bad = torch.from_numpy(np.full(H, H * 7, dtype=np.int32)).cuda()
+    dev.render_device(cam, params[0], bad.data_ptr(), H, again.data_ptr(), streams[0].cuda_stream, None, asynchronous=True)
+    with pytest.raises(F.RtError) as e:
+        dev.wait(streams[0].cuda_stream)
+    assert "row id" in str(e.value)
+    dev.render_device(cam, params[0], d_rows.data_ptr(), H, again.data_ptr(), streams[0].cuda_stream, None, asynchronous=True)   # and the stream is usable again
+    dev.wait(streams[0].cuda_stream)
+    assert np.array_equal(bits(again.cpu().numpy()), bits(outs[0].cpu().numpy()))
+
+
 def test_full_size_properties_of_the_headline_config(rt, O):
     """At BASELINE's full image size (800x800, book-2 final scene) the oracle cannot render the frame, so:
     (1) rows rendered separately == rows rendered together (sharding invariance, multi-GPU);
