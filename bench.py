@@ -585,7 +585,9 @@ def main():
         # Which traversal variant ran: with the node table in LDS the node bytes never reach L1 / L2 (primitives still do).
         tv = dscene.trace_variant()
         nodes_in_lds = tv["nodes_in_lds"] >= scene.desc.n_nodes and tv["nodes_in_lds"] > 0
-        lds_bytes = BYTES_NODE_LDS * counts["node_visits"] if nodes_in_lds else 0
+        # (the sphere-only instance tests node boxes in single precision: 3 x 8 B of box + 8 B of child refs per visit)
+        node_lds = 32 if tv.get("f32_slabs") else BYTES_NODE_LDS
+        lds_bytes = node_lds * counts["node_visits"] if nodes_in_lds else 0
         cache_bytes = ab["traversal"] - (BYTES_NODE * counts["node_visits"] if nodes_in_lds else 0)
         if tv.get("spheres_in_lds"):       # (small sphere-only scenes: both sphere pools are LDS tables too, 36 / 80 B per test)
             k_s, k_m = F.KIND_NAMES.index("sphere"), F.KIND_NAMES.index("moving_sphere")
@@ -678,8 +680,10 @@ def main():
         if nodes_in_lds:
             roof["lds"] = {"achieved": rnd(gbs(lds_bytes, tr_ms)), "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s", "frac": frac(gbs(lds_bytes, tr_ms), LDS_PEAK_GBS),
                            "bytes_per_step": int(lds_bytes),
-                           "what": "%d B per node visit from the workgroup's node table (3 x ds_read_b128 + ds_read_b64 at random records: bank conflicts "
-                                   "make the usable rate a third to a quarter of the conflict-free peak)%s" % (BYTES_NODE_LDS, "; the sphere pools too" if tv.get("spheres_in_lds") else "")}
+                           "what": "%d B per node visit from the workgroup's node table (%s at random records: bank conflicts "
+                                   "make the usable rate a third to a quarter of the conflict-free peak)%s"
+                                   % (node_lds, "4 x ds_read2_b32: float boxes, single-precision slab test" if tv.get("f32_slabs") else "3 x ds_read_b128 + ds_read_b64",
+                                      "; the sphere pools too" if tv.get("spheres_in_lds") else "")}
             limiter.append(("lds", roof["lds"]["frac"]))
         measured = pmc and "wf_trace" in pmc and roof.get("valu") and roof.get("hbm_counter")
         if measured:
@@ -706,7 +710,8 @@ def main():
                                                          "cache-served bytes are still priced against HBM" % pmc_note}
         note = ["scene %.2f MB (%s the 32 MiB of aggregate L2)" % (sbytes / 1e6, "fits" if sbytes <= L2_BYTES else "exceeds")]
         if nodes_in_lds:
-            note.append("traversal variant: %d-thread workgroups, all %d node records in LDS" % (tv["workgroup_threads"], tv["nodes_in_lds"]))
+            note.append("traversal variant: %d-thread workgroups, all %d node records in LDS%s" % (tv["workgroup_threads"], tv["nodes_in_lds"],
+                        " as floats (single-precision slab test, double-precision second opinion where the two could differ)" if tv.get("f32_slabs") else ""))
         if roof.get("hbm_counter"):
             note.append("measured HBM traffic of wf_trace %.0f B per ray segment = %.2f of the 8 TB/s peak, against SURVEY §8(d)'s nominal %.2f: "
                         "the node and primitive bytes are served by %s" % (roof["hbm_counter"]["bytes_per_ray"], roof["hbm_counter"]["frac"], sec8d["frac"] or 0,

@@ -367,7 +367,7 @@ def test_single_precision_slab_test_on_hostile_spheres(rt, O):
         ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=4, want_stats=True)
         dev = rt.DeviceScene(d)
         v = dev.trace_variant()
-        assert v["spheres_in_lds"] and v["nodes_in_lds"] == d.n_nodes, (label, v)     # (the instance with the single-precision test)
+        assert v["spheres_in_lds"] and v["f32_slabs"] and v["nodes_in_lds"] == d.n_nodes, (label, v)     # (the instance with the single-precision test)
         out, st = dev.render(cam, p, rows, want_stats=True)
         assert st.as_dict() == st_ref.as_dict(), label
         assert np.array_equal(bits(out), bits(ref)), label
