@@ -37,6 +37,10 @@ struct MaterialDev {
 // Pointers into HBM, one pool per kind (layouts = include/rt2022.h).
 struct SceneDev {
     const rt_bvh_node *nodes;
+    // The node table once more in single precision, 32 bytes per node: {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref}
+    // (floats rounded to nearest from the doubles of `nodes`, same numbering) — what the sphere-scene traversal kernels that cannot
+    // keep the whole table in LDS fetch per node step (wf_trace, kF32G; the double-precision record serves the undecided steps).
+    const uint32_t *nodes32;
     const rt_sphere *spheres;
     const rt_moving_sphere *moving_spheres;
     const rt_rect *rects;

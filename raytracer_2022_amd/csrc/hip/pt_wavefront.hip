@@ -64,6 +64,9 @@ typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));     // 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RT2022_F32_GLOBAL
+#define RT2022_F32_GLOBAL 1            // the same test on 32-byte single-precision node records from HBM / L2 for the sphere scenes too large for LDS (wf_trace, kF32G)
+#endif
 #ifndef RT2022_F32_SLABS
 #define RT2022_F32_SLABS 1             // node table in LDS: single-precision slab test with a double-precision second opinion (wf_trace, t_slabs32):
                                        // 1 the all-in-LDS instance of sphere-only scenes, 2 every instance that holds the whole table (A/B, census), 0 none
@@ -929,6 +932,21 @@ RT_DEV void t_slabs32(TLane &L, uint32_t table_at) {
     }
     L.e_ray = ok ? __builtin_fmaf(e, kF32RayBound, 2e-8f) : __builtin_inff();
 }
+// The same for the kernels that fetch their single-precision records from HBM (kF32G): no per-lane table addresses, the record's
+// {min, max} pairs are ordered after the multiply-adds instead.
+RT_DEV void t_slabs32g(TLane &L) {
+    float e = 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float i32 = (float)L.inv[i], n32 = (float)(-(L.cur.o[i] * L.inv[i]));
+        L.p32[i] = (f32x2){i32, n32};
+        e = __builtin_fmaxf(e, __builtin_fabsf(n32));
+        const float ai = __builtin_fabsf(i32);
+        ok = ok && ai >= 1e-30f && ai <= 1e30f;
+    }
+    L.e_ray = ok ? __builtin_fmaf(e, kF32RayBound, 2e-8f) : __builtin_inff();
+}
 RT_DEV void t_set_cur(TLane &L, const XRay &c, bool boxes_plain) {
     L.cur = c;
     L.inv = Vec3(1.0 / c.d.x, 1.0 / c.d.y, 1.0 / c.d.z);
@@ -1093,9 +1111,16 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // Cornell box's 6 % slower, whether the undecided lanes fetch the double-precision box on the spot or hand the step to the
     // voted arm (profiles/r3q_ab_f32_slabs.log).
     constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
-    __shared__ f64x2 nc_box[CACHE > 0 && !kF32 ? 3 * CACHE : 1];
-    __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 ? CACHE : 1];
+    // (kF32G) The same test for sphere scenes too large for that instance (FEAT 0: the plain kernels and the partial-table one):
+    // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
+    // two 16-byte loads, from HBM / L2 or, for the first kCache32 of them, from LDS; half the bytes of the double-precision
+    // record per node step, and in a partial table 3 045 records instead of 1 740.
+    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && FEAT == 0 && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+    constexpr int kCache32 = kF32G && CACHE > 0 ? CACHE * 56 / 32 : 0;
+    __shared__ f64x2 nc_box[CACHE > 0 && !kF32 && !kF32G ? 3 * CACHE : 1];
+    __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 && !kF32G ? CACHE : 1];
     __shared__ uint32_t nc32[kF32 ? kNode32Words * CACHE : 1];
+    __shared__ u32x4 nc32g[kCache32 ? 2 * kCache32 : 1];
     // ... and, in every variant (384 bytes), the first records of the two small tables the arms go to most: movers (32 B
     // each) and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
 #ifndef RT2022_SMALL_TABLES_EVERYWHERE
@@ -1115,8 +1140,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
     TStack<STACK, WG> st{stack_lds + tid};
-    const uint32_t n_cached = CACHE > 0 ? (s.n_nodes < (uint32_t)CACHE ? s.n_nodes : (uint32_t)CACHE) : 0u;
-    if (CACHE > 0) {
+    constexpr uint32_t kTableRecords = kF32G ? (uint32_t)kCache32 : (uint32_t)CACHE;
+    const uint32_t n_cached = CACHE > 0 ? (s.n_nodes < kTableRecords ? s.n_nodes : kTableRecords) : 0u;
+    if (kCache32) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(s.nodes32);
+        for (uint32_t i = tid; i < 2u * n_cached; i += (uint32_t)WG) nc32g[i] = src[i];
+    }
+    if (CACHE > 0 && !kF32G) {
         for (uint32_t i = tid; i < n_cached; i += (uint32_t)WG) {
             const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + i);
             f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
@@ -1239,6 +1269,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     L.near_at[0] = L.near_at[1] = L.near_at[2] = L.far_at[0] = L.far_at[1] = L.far_at[2] = table_at;
     L.p32[0] = L.p32[1] = L.p32[2] = (f32x2){0.0f, 0.0f}; L.e_ray = __builtin_inff();
     uint32_t refs32_at = table32_at + 36u;                             // (kF32: the child refs of record 0)
+    uint32_t table32g_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) u32x4 *)nc32g;
+    if (kCache32) asm volatile("" : "+v"(table32g_at));
     if (kF32) asm volatile("" : "+v"(refs32_at));
 
     for (;;) {
@@ -1252,7 +1284,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         // of it, and all that are left go together when their count falls below the threshold.
         {
             // a node step (OP_NODE is label 0) of a plain ray — and not one the single-precision test has handed on: one compare, one vote
-            bool isn = kF32 ? (L.op | ((L.flags ^ kPlain) & (kPlain | kNeed64))) == 0u : (L.op | (~L.flags & kPlain)) == 0u;
+            bool isn = (kF32 || kF32G) ? (L.op | ((L.flags ^ kPlain) & (kPlain | kNeed64))) == 0u : (L.op | (~L.flags & kPlain)) == 0u;
             int nn = __popcll(wballot(isn));
             const int pending = __popcll(wballot(L.op != OP_IDLE));
             const int tail_threshold = tail_factor * pending / (tail_factor + 1) + 1;
@@ -1264,7 +1296,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             // (kF32) the window's ends in single precision and the error bound of this entry: the ray's share plus what the
             // two conversions can be off by (an infinite end converts exactly)
             float tlo32 = 0.0f, thi32 = 0.0f;
-            if (kF32 && entered) {
+            if ((kF32 || kF32G) && entered) {
                 tlo32 = (float)tlo_c; thi32 = (float)thi_c;
                 asm volatile("" : "+v"(tlo32), "+v"(thi32));
             }
@@ -1336,6 +1368,57 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     }
 #endif
                     left = cr.x; right = cr.y;
+                } else if (kF32G) {
+                    // The single-precision test on the 32-byte record (see kF32G above): {min, max} of an axis are one register pair,
+                    // one packed multiply-add gives the axis' two slab distances, ordered afterwards (a min and a max per axis —
+                    // no per-lane addresses here: one base address serves both loads).
+                    u32x4 q0, q1;
+                    if (kCache32 && nidx < n_cached) {
+                        uint32_t at;
+                        asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(at) : "v"(nidx), "v"(table32g_at));
+                        const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
+                        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(q0), "=&v"(q1), "=&v"(below) : "v"(at), "v"(below_at) : "memory");
+                    } else {
+                        const u32x4 *np = reinterpret_cast<const u32x4 *>(s.nodes32) + 2u * (uint64_t)nidx;
+                        q0 = np[0]; q1 = np[1];
+                        below = st.col[below_sp * WG];
+                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(below));          // (both halves and the stack entry asked for together)
+                    }
+                    const f32x2 bx = {__uint_as_float(q0.x), __uint_as_float(q0.y)}, by = {__uint_as_float(q0.z), __uint_as_float(q0.w)},
+                                bz = {__uint_as_float(q1.x), __uint_as_float(q1.y)};
+                    f32x2 tx, ty, tz;
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tx) : "v"(bx), "v"(L.p32[0]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(ty) : "v"(by), "v"(L.p32[1]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "v"(bz), "v"(L.p32[2]));
+                    float nx, ny, nz, fx, fy, fz, tmn32, tmx32;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y)); asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y)); asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y)); asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmn32) : "v"(nx), "v"(ny), "v"(nz));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmx32) : "v"(fx), "v"(fy), "v"(fz));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(tmn32) : "v"(tmn32), "v"(tlo32));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(tmx32) : "v"(tmx32), "v"(thi32));
+                    const float gap = tmx32 - tmn32;
+                    hit = gap > 0.0f;
+                    const float e_tot = __builtin_fmaf(__builtin_fabsf(tmx32) + __builtin_fabsf(tmn32), kF32RelBound, L.e_ray);
+                    undecided = !(__builtin_fabsf(gap) > e_tot);                   // (a NaN anywhere lands here too)
+#ifdef RT2022_F32_CENSUS
+                    f32_steps++; if (undecided) f32_undecided++;
+                    if (!undecided) {
+                        const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + nidx);
+                        const f64x2 n0 = np[0], n1 = np[1], n2 = np[2];
+                        const double lo3[3] = {n0.x, n0.y, n1.x}, hi3[3] = {n1.y, n2.x, n2.y};
+                        double tmn = tlo_c, tmx = thi_c;
+                        for (int i = 0; i < 3; i++) {
+                            const double t0 = (lo3[i] - L.cur.o[i]) * L.inv[i], t1 = (hi3[i] - L.cur.o[i]) * L.inv[i];
+                            tmn = __builtin_fmax(tmn, __builtin_fmin(t0, t1));
+                            tmx = __builtin_fmin(tmx, __builtin_fmax(t0, t1));
+                        }
+                        if (hit != !(tmx <= tmn)) f32_wrong++;
+                    }
+#endif
+                    left = q1.z; right = q1.w;
                 } else {
                 if (CACHE > 0 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                     // (LDS addresses are 32 bits and a table index is far below 2^24: one v_mad_u32_u24 instead of a 64-bit multiply-add)
@@ -1396,7 +1479,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 // movers (media, movers, nodes, lists) is really visited twice. rt_scene_create has
                 // worked that out per node: `right` here is the node's PUSH REF — its right child, or
                 // REF_EMPTY where the twin needs no second visit (r3: one compare instead of five).
-                if (kF32 && undecided) {
+                if ((kF32 || kF32G) && undecided) {
                     // Mostly a ray leaving a surface against a box that surface lies on the face of: the verdict hangs on t_min = 0.001
                     // against a distance of zero, which floats of the scene's size cannot tell apart. The lane keeps its node and leaves
                     // the loop; the voted node arm takes the step on the double-precision record (no lane here waits for that fetch).
@@ -1473,7 +1556,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             }
             if (kF32 && decided) {
                 n0 = n1 = n2 = (f64x2){0.0, 0.0};
-            } else if (CACHE > 0 && !kF32 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
+            } else if (CACHE > 0 && !kF32 && !kF32G && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first; kF32G: the voted steps — below the quorum, not plain, or undecided — take the double-precision record from L2)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const u32x2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, 0u, cr.y, 0u};
@@ -1497,7 +1580,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 miss = miss || (tmx <= tmn);
             }
             }
-            if (kF32) L.flags &= ~kNeed64;
+            if (kF32 || kF32G) L.flags &= ~kNeed64;
             if (!miss) {
                 const uint32_t left = n3.x, push_ref = n3.z;           // (push ref: see the fast path)
                 if (push_ref == REF_EMPTY) cnt.prim(RT_REF_KIND(left));
@@ -1734,7 +1817,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     L.a_len = L.cur.d.length_sqr();
                 }
                 t_flags(L, boxes_plain);
-                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
+                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at); if (kF32G) t_slabs32g(L);
                 T_NEXT();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
@@ -1762,7 +1845,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                         L.cur.o = L.cur.o / p0;
                     }
                     t_flags(L, boxes_plain);
-                    if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
+                    if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at); if (kF32G) t_slabs32g(L);
                     L.ctx.push(L.top);
                     st.push(L, REF_POPCTX);
                     L.top = x0.y;
@@ -1847,7 +1930,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 L.tm = wr.tm;
                 L.rng = Rng(rs);
                 t_set_cur(L, XRay{wr.orig, wr.dir}, boxes_plain);
-                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at);
+                if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at); if (kF32G) t_slabs32g(L);
                 if (FEAT & kFeatMovers) L.stash_level = 0xFFFFFFFFu;
                 if (kStash) {                                         // what leaving a mover goes back to (OP_CTX)
                     wray[0 * WG] = wr.orig.x; wray[1 * WG] = wr.orig.y; wray[2 * WG] = wr.orig.z;
@@ -2250,7 +2333,9 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
     out[3] = 0;
     const int table = node_cache_mode(scene, stack_need, tuning, features);
     if (table) {
-        out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < (uint32_t)kNodeCache ? scene.n_nodes : (uint32_t)kNodeCache;
+        // (a partial table of a FEAT-0 scene holds 32-byte single-precision records: kF32G)
+        const uint32_t cap = (table == 2 && features == 0 && RT2022_F32_SLABS >= 1 && RT2022_F32_GLOBAL) ? (uint32_t)kNodeCache * 56u / 32u : (uint32_t)kNodeCache;
+        out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < cap ? scene.n_nodes : cap;
         out[3] = table == 3 ? 1u : 0u;
         return;
     }

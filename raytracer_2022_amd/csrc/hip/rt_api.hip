@@ -689,6 +689,17 @@ int rt_scene_create(const rt_scene_desc *desc, rt_scene **out) {
                     nodes[new_of[i]] = q;
                 }
                 s.nodes = upload(nodes.data(), nodes.size(), sc->owned);
+                std::vector<uint32_t> n32((size_t)8 * nodes.size() + 8);         // (never empty: upload of nothing is a null pointer)
+                for (size_t i = 0; i < nodes.size(); i++) {
+                    const rt_bvh_node &q = nodes[i];
+                    for (int ax = 0; ax < 3; ax++) {
+                        const float lo = (float)q.bmin[ax], hi = (float)q.bmax[ax];
+                        std::memcpy(&n32[8 * i + 2 * ax], &lo, 4);
+                        std::memcpy(&n32[8 * i + 2 * ax + 1], &hi, 4);
+                    }
+                    n32[8 * i + 6] = q.left; n32[8 * i + 7] = q._pad[0];
+                }
+                s.nodes32 = upload(n32.data(), n32.size(), sc->owned);
             }
             // Primitive pools go up with the slot kind of their material packed above the material index (pt_device.h).
             RT_REQUIRE(desc->n_materials <= kMatIndexMask, RT_ERR_UNSUPPORTED, "more than 2^24 materials");
