@@ -65,7 +65,9 @@ int rt_debug_valu_probe(int mode, uint32_t iters);
 int rt_debug_scene_info(const rt_scene *scene, uint32_t *stack_need, int32_t *grid_blocks);
 /* The traversal kernel variant the scene's timed renders (no RT_FLAG_COUNTERS) take: threads per workgroup, stack
  * entries per lane, how many of the scene's node records the workgroup keeps in LDS (0: the plain kernels, every
- * node fetched through L1 / L2), and whether its Sphere / MovingSphere pools are there too (1: small sphere-only scenes). */
+ * node fetched through L1 / L2), and in *spheres_in_lds two flags: bit 0 — its Sphere / MovingSphere pools are there too (small
+ * sphere-only scenes); bit 1 — it tests node boxes in single precision, with the double-precision test wherever the two could
+ * differ (sphere scenes: 44-byte records in LDS, or 32-byte records from HBM / L2 and a partial LDS table). */
 int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, uint32_t *stack_entries, uint32_t *nodes_in_lds,
                            uint32_t *spheres_in_lds);
 /* The single-precision slab test of the traversal kernel for sphere-only scenes: out[3] = the build's

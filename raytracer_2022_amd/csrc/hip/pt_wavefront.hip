@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
     // two 16-byte loads, from HBM / L2 or, for the first kCache32 of them, from LDS; half the bytes of the double-precision
     // record per node step, and in a partial table 3 045 records instead of 1 740.
-    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && FEAT == 0 && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : FEAT == 0) && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
     constexpr int kCache32 = kF32G && CACHE > 0 ? CACHE * 56 / 32 : 0;
     __shared__ f64x2 nc_box[CACHE > 0 && !kF32 && !kF32G ? 3 * CACHE : 1];
     __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 && !kF32G ? CACHE : 1];
@@ -2332,16 +2332,22 @@ hipError_t f32_slab_census(unsigned long long out[5]) {
 void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features, uint32_t out[4]) {
     out[3] = 0;
     const int table = node_cache_mode(scene, stack_need, tuning, features);
+    // Which instances test node boxes in single precision (wf_trace: kF32, kF32G) — bit 1 of out[3]
+    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes) : (RT2022_F32_GLOBAL == 1 && features == 0));
+    const bool f32 = table == 3 ? RT2022_F32_SLABS == 1 || RT2022_F32_SLABS == 2
+                   : table == 1 ? RT2022_F32_SLABS == 2 && !(features & kFeatMisc)
+                   : f32_global;
     if (table) {
-        // (a partial table of a FEAT-0 scene holds 32-byte single-precision records: kF32G)
-        const uint32_t cap = (table == 2 && features == 0 && RT2022_F32_SLABS >= 1 && RT2022_F32_GLOBAL) ? (uint32_t)kNodeCache * 56u / 32u : (uint32_t)kNodeCache;
+        // (a partial table under kF32G holds 32-byte single-precision records)
+        const uint32_t cap = (table == 2 && f32_global) ? (uint32_t)kNodeCache * 56u / 32u : (uint32_t)kNodeCache;
         out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < cap ? scene.n_nodes : cap;
-        out[3] = table == 3 ? 1u : 0u;
+        out[3] = (table == 3 ? 1u : 0u) | (f32 ? 2u : 0u);
         return;
     }
     out[0] = (uint32_t)kBlock;
     out[1] = stack_need <= (uint32_t)kStackSmall ? (uint32_t)kStackSmall : stack_need <= (uint32_t)kStackMid ? (uint32_t)kStackMid : (uint32_t)kStackLarge;
     out[2] = 0;
+    out[3] = f32 ? 2u : 0u;
 }
 
 hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args, const RenderArgs *d_args,

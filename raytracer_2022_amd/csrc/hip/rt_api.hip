@@ -1296,7 +1296,7 @@ int rt_debug_trace_variant(const rt_scene *scene, uint32_t *workgroup_threads, u
         if (workgroup_threads) *workgroup_threads = v[0];
         if (stack_entries) *stack_entries = v[1];
         if (nodes_in_lds) *nodes_in_lds = v[2];
-        if (spheres_in_lds) *spheres_in_lds = v[3];
+        if (spheres_in_lds) *spheres_in_lds = v[3];           // (bit 0: the sphere pools are in LDS; bit 1: node boxes are tested in single precision)
         return RT_OK;
     });
 }

@@ -22,10 +22,8 @@ class DeviceScene:
         """The traversal kernel variant timed renders of this scene take (rt_debug_trace_variant)."""
         wg, st, nc, sp = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         F.check(F.lib().rt_debug_trace_variant(self._h, C.byref(wg), C.byref(st), C.byref(nc), C.byref(sp)))
-        v = (C.c_uint64 * 5)()
-        F.check(F.lib().rt_debug_f32_slabs(v))       # (v[3]: 1 = the single-precision slab test is in the all-in-LDS instance of sphere-only scenes)
-        return {"workgroup_threads": wg.value, "stack_entries": st.value, "nodes_in_lds": nc.value, "spheres_in_lds": bool(sp.value),
-                "f32_slabs": bool(sp.value) and v[3] == 1}
+        return {"workgroup_threads": wg.value, "stack_entries": st.value, "nodes_in_lds": nc.value, "spheres_in_lds": bool(sp.value & 1),
+                "f32_slabs": bool(sp.value & 2)}
 
     def set_tuning(self, node_quorum=18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24), vote_weights=0):
         F.check(F.lib().rt_debug_set_tuning(self._h, node_quorum, vote_weights))

@@ -373,6 +373,11 @@ def test_single_precision_slab_test_on_hostile_spheres(rt, O):
         assert np.array_equal(bits(out), bits(ref)), label
         assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), label       # (the timed kernel: the one that holds the test)
         assert st_ref.node_visits > 0 and st_ref.rays > W * H * spp, label
+        # ... and the plain kernel of sphere scenes (what a scene too large for LDS takes): the same test on 32-byte records from L2 / HBM
+        dev.set_tuning(18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24) | (1 << 28))
+        v2 = dev.trace_variant()
+        assert v2["nodes_in_lds"] == 0 and v2["f32_slabs"], (label, v2)
+        assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), label
 
 
 def test_scheduling_knobs_never_change_results(rt, O):
@@ -628,6 +633,7 @@ def test_node_table_variant_gives_the_same_bits(rt):
     dev = rt.DeviceScene(big.desc)
     v = dev.trace_variant()
     assert v["workgroup_threads"] == 1024 and 0 < v["nodes_in_lds"] < big.desc.n_nodes and v["stack_entries"] >= dev.info()["stack_need"], v
+    assert v["f32_slabs"] and v["nodes_in_lds"] == 1740 * 56 // 32, v      # (a sphere scene: 32-byte single-precision records, 3 045 of them in LDS)
     cam, bg = big.default_view(16 / 9)
     p = rt.make_params(64, 36, 2, 50, bg, seed=5)
     rows = np.arange(36, dtype=np.uint32)
@@ -635,6 +641,8 @@ def test_node_table_variant_gives_the_same_bits(rt):
     dev.set_tuning(default | (1 << 28))
     assert dev.trace_variant()["nodes_in_lds"] == 0
     assert np.array_equal(bits(a), bits(dev.render(cam, p, rows)))
+    from oracle import oracle_ffi as O_
+    assert np.array_equal(bits(a), bits(O_.render_cpu(big.desc, cam, p, rows, n_threads=4)))      # (both against the oracle, not only each other)
     # ... and a BVH too deep for stacks of 16 entries takes the plain kernels
     deep = rt.HostScene("wwscene", seed=5, param=1)
     assert rt.DeviceScene(deep.desc).trace_variant()["nodes_in_lds"] == 0
