@@ -1799,9 +1799,20 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             // 1/d of the ray changes only where d does: RotateY (x and z). Translate and Zoom leave the direction alone
             // (hittable/mod.rs:165-167,321-323), so entering or leaving them keeps inv and a_len — the same values the
             // three divisions would give again.
+#ifndef RT2022_CTX_CHAINS
+#define RT2022_CTX_CHAINS 1            // movers nested directly in one another (Translate(RotateY(Zoom(..))), scene.rs:320-322,403-412) are entered, and left, in ONE turn
+#endif
             if (L.top == REF_POPCTX) {
-                L.ctx.n--;
-                const uint32_t left_kind = RT_REF_KIND(L.ctx.at(L.ctx.n));           // the mover being left
+                // Leaving a mover. When the next stack entry is the exit of the enclosing mover too — the movers were nested directly,
+                // nothing else waits in the frames between — all of them are left in this turn: only the outermost frame's ray is ever
+                // used again (r3b: three turns, three world-ray fetches and three re-derivations became one for the meshes of wwscene).
+                bool rotated = false;
+                uint32_t levels = 0;
+                do {
+                    L.ctx.n--;
+                    rotated = rotated || RT_REF_KIND(L.ctx.at(L.ctx.n)) == RT_KIND_ROTATE_Y;           // (a mover being left)
+                    L.top = st.pop(L);
+                } while (RT2022_CTX_CHAINS && L.top == REF_POPCTX && L.ctx.n > 0u && ++levels < RT_MAX_XFORM_DEPTH);
                 // the world ray from this lane's LDS column (written at refill), then back down to the enclosing frame
                 XRay world;
                 if (kStash) {
@@ -1811,46 +1822,60 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     world = XRay{wr.orig, wr.dir};
                 }
                 L.cur = ray_at(L.ctx, L.ctx.n, world);
-                if (left_kind == RT_KIND_ROTATE_Y) {
-                    if (L.stash_level == L.ctx.n) { L.inv.x = L.stash_ix; L.inv.z = L.stash_iz; L.stash_level = 0xFFFFFFFFu; }
+                if (rotated) {
+                    // 1/d.x, 1/d.z of the frame arrived in: the stash holds them for the frame its RotateY was entered from — this one, or
+                    // one whose direction is this one's (only a RotateY changes d); otherwise the two divisions again (same values).
+                    bool stash_ok = L.stash_level != 0xFFFFFFFFu && L.stash_level >= L.ctx.n;
+                    for (uint32_t j = L.ctx.n; stash_ok && j < L.stash_level && j < RT_MAX_XFORM_DEPTH; j++)
+                        stash_ok = RT_REF_KIND(L.ctx.at(j)) != RT_KIND_ROTATE_Y;
+                    if (stash_ok) { L.inv.x = L.stash_ix; L.inv.z = L.stash_iz; }
                     else { L.inv.x = 1.0 / L.cur.d.x; L.inv.z = 1.0 / L.cur.d.z; }
+                    L.stash_level = 0xFFFFFFFFu;
                     L.a_len = L.cur.d.length_sqr();
                 }
                 t_flags(L, boxes_plain);
                 if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at); if (kF32G) t_slabs32g(L);
-                T_NEXT();
+                T_SETTLE();
             } else {
                 uint32_t kind = RT_REF_KIND(L.top), idx = RT_REF_INDEX(L.top);
-                cnt.prim(kind);
                 if (kind == RT_KIND_LIST) {
+                    cnt.prim(kind);
                     const rt_list &l = s.lists[idx];
                     for (uint32_t i = l.count; i > 0; i--) st.push(L, s.list_items[l.first + i - 1]);
                     T_NEXT();
                 } else if (L.ctx.n < RT_MAX_XFORM_DEPTH) {
-                    u32x4 x0;                                         // rt_xform, 32 B: kind, child, p[3]
-                    f64x2 x1;
-                    xform_words(idx, x0, x1);
-                    t_pin(x0); t_pin(x1);
-                    const double p0 = rtm::u2d(((uint64_t)x0.w << 32) | x0.z), p1 = x1.x, p2 = x1.y;
-                    if (kind == RT_KIND_TRANSLATE) {                  // Translate::hit, mod.rs:165-167
-                        L.cur.o = L.cur.o - Vec3(p0, p1, p2);
-                    } else if (kind == RT_KIND_ROTATE_Y) {            // RotateY::hit, mod.rs:235-247 (p0 = sin, p1 = cos)
-                        const double ox = p1 * L.cur.o.x - p0 * L.cur.o.z, oz = p0 * L.cur.o.x + p1 * L.cur.o.z;
-                        const double dx = p1 * L.cur.d.x - p0 * L.cur.d.z, dz = p0 * L.cur.d.x + p1 * L.cur.d.z;
-                        L.cur.o.x = ox; L.cur.o.z = oz; L.cur.d.x = dx; L.cur.d.z = dz;
-                        L.stash_ix = L.inv.x; L.stash_iz = L.inv.z; L.stash_level = L.ctx.n;
-                        L.inv.x = 1.0 / dx; L.inv.z = 1.0 / dz;
-                        L.a_len = L.cur.d.length_sqr();
-                    } else {                                          // Zoom::hit, mod.rs:321-323: the origin only
-                        L.cur.o = L.cur.o / p0;
+                    // Entering a mover — and, in the same turn, the movers its child is wrapped in directly.
+#pragma unroll 1
+                    for (uint32_t rep = 0; rep < RT_MAX_XFORM_DEPTH; rep++) {
+                        cnt.prim(kind);
+                        u32x4 x0;                                     // rt_xform, 32 B: kind, child, p[3]
+                        f64x2 x1;
+                        xform_words(idx, x0, x1);
+                        t_pin(x0); t_pin(x1);
+                        const double p0 = rtm::u2d(((uint64_t)x0.w << 32) | x0.z), p1 = x1.x, p2 = x1.y;
+                        if (kind == RT_KIND_TRANSLATE) {              // Translate::hit, mod.rs:165-167
+                            L.cur.o = L.cur.o - Vec3(p0, p1, p2);
+                        } else if (kind == RT_KIND_ROTATE_Y) {        // RotateY::hit, mod.rs:235-247 (p0 = sin, p1 = cos)
+                            const double ox = p1 * L.cur.o.x - p0 * L.cur.o.z, oz = p0 * L.cur.o.x + p1 * L.cur.o.z;
+                            const double dx = p1 * L.cur.d.x - p0 * L.cur.d.z, dz = p0 * L.cur.d.x + p1 * L.cur.d.z;
+                            L.cur.o.x = ox; L.cur.o.z = oz; L.cur.d.x = dx; L.cur.d.z = dz;
+                            L.stash_ix = L.inv.x; L.stash_iz = L.inv.z; L.stash_level = L.ctx.n;
+                            L.inv.x = 1.0 / dx; L.inv.z = 1.0 / dz;
+                            L.a_len = L.cur.d.length_sqr();
+                        } else {                                      // Zoom::hit, mod.rs:321-323: the origin only
+                            L.cur.o = L.cur.o / p0;
+                        }
+                        L.ctx.push(L.top);
+                        st.push(L, REF_POPCTX);
+                        L.top = x0.y;
+                        kind = RT_REF_KIND(L.top); idx = RT_REF_INDEX(L.top);
+                        if (!(RT2022_CTX_CHAINS && kind >= RT_KIND_TRANSLATE && kind <= RT_KIND_ZOOM && L.ctx.n < RT_MAX_XFORM_DEPTH)) break;
                     }
                     t_flags(L, boxes_plain);
                     if (kSlabs) t_slabs(L, table_at); if (kF32) t_slabs32(L, table_at); if (kF32G) t_slabs32g(L);
-                    L.ctx.push(L.top);
-                    st.push(L, REF_POPCTX);
-                    L.top = x0.y;
                     T_SETTLE();
                 } else {
+                    cnt.prim(kind);
                     T_NEXT();
                 }
             }
