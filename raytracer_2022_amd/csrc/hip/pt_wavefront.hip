@@ -1527,6 +1527,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
         if (L.op != (uint32_t)best) {
             // parked: this lane's operation did not win the vote
         } else if (best == OP_NODE) {
+            // (a node step below the fast path's quorum — a handful of lanes: those whose next entry is a node again take it in the
+            // same turn, like the leaf arms do with their pairs)
+#ifndef RT2022_NODE_REPS
+#define RT2022_NODE_REPS 1
+#endif
+#pragma unroll 1
+            for (int rep = 0; rep < RT2022_NODE_REPS && L.op == OP_NODE; rep++) {
             cnt.node();
             L.steps++;
             const uint32_t nidx = RT_REF_INDEX(L.top);
@@ -1590,6 +1597,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             } else {
                 L.top = st.pop(L);
                 L.op = classify(L.top);
+            }
             }
         } else if (best == OP_SPHERE) {                               // Sphere / MovingSphere::hit
             // BVH leaves come in pairs (span-2 nodes): a lane whose next entry is a sphere again takes
