@@ -1088,7 +1088,9 @@ constexpr int trace_waves_per_simd(int stack, bool stats, unsigned feat, int wg)
 }
 // FEAT: which arms the scene can reach (kFeat* bits); the others are compiled out, which is
 // worth 20-60 VGPRs — the difference between 3 and 4-5 resident waves per SIMD.
-template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false, bool PRIMS = false>
+// SPHERES: every primitive of the scene is a sphere (FEAT 0 and no rects) — the scenes whose node boxes are tested in single precision
+// (a rect lies in the faces of its box, where that test decides nothing: see kF32 below).
+template <int STACK, bool STATS, unsigned FEAT, bool PROBE = false, int WG = kBlock, int CACHE = 0, bool PARTIAL = false, bool PRIMS = false, bool SPHERES = false>
 __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, WG)) wf_trace(const SceneDev s, const WfPool pool,
                                                    const double t_min, const uint32_t node_quorum_u, const uint32_t parity, StatsDev *stats,
                                                    const uint32_t vote_weights) {
@@ -1111,11 +1113,11 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // Cornell box's 6 % slower, whether the undecided lanes fetch the double-precision box on the spot or hand the step to the
     // voted arm (profiles/r3q_ab_f32_slabs.log).
     constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
-    // (kF32G) The same test for sphere scenes too large for that instance (FEAT 0: the plain kernels and the partial-table one):
+    // (kF32G) The same test for sphere scenes too large for that instance (SPHERES: the plain kernels and the partial-table one):
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
     // two 16-byte loads, from HBM / L2 or, for the first kCache32 of them, from LDS; half the bytes of the double-precision
     // record per node step, and in a partial table 3 045 records instead of 1 740.
-    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : FEAT == 0) && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : (FEAT == 0 && SPHERES)) && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
     constexpr int kCache32 = kF32G && CACHE > 0 ? CACHE * 56 / 32 : 0;
     __shared__ f64x2 nc_box[CACHE > 0 && !kF32 && !kF32G ? 3 * CACHE : 1];
     __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 && !kF32G ? CACHE : 1];
@@ -2059,6 +2061,13 @@ static void launch_trace(const WfLaunch &w, uint32_t parity) {
     uint32_t grid = per_cu * (w.pool.n_cus ? w.pool.n_cus : 1u);
     const uint32_t most = w.blocks * ((uint32_t)S / kChunk / 4u);
     if (grid > most) grid = most;
+    if constexpr (FEAT == 0 && !STATS && !PROBE) {
+        if (w.scene.n_rects == 0) {                                   // a sphere-only scene: the instance that tests node boxes in single precision (kF32G)
+            hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE, kBlock, 0, false, false, true>), dim3(grid), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
+                               w.node_quorum, parity, w.stats, w.vote_weights);
+            return;
+        }
+    }
     hipLaunchKernelGGL((wf_trace<STACK, STATS, FEAT, PROBE>), dim3(grid), dim3(kBlock), 0, w.stream, w.scene, w.pool, w.t_min,
                        w.node_quorum, parity, w.stats, w.vote_weights);
 }
@@ -2068,6 +2077,13 @@ static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
     const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
     if (grid > most) grid = most;
+    if constexpr (FEAT == 0 && PARTIAL) {
+        if (w.scene.n_rects == 0) {                                   // (a sphere-only scene: single-precision records in the partial table and beyond it)
+            hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL, false, true>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
+                               w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
+            return;
+        }
+    }
     hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
                        w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
 }
@@ -2366,7 +2382,7 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
     out[3] = 0;
     const int table = node_cache_mode(scene, stack_need, tuning, features);
     // Which instances test node boxes in single precision (wf_trace: kF32, kF32G) — bit 1 of out[3]
-    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes) : (RT2022_F32_GLOBAL == 1 && features == 0));
+    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes) : (RT2022_F32_GLOBAL == 1 && features == 0 && scene.n_rects == 0));
     const bool f32 = table == 3 ? RT2022_F32_SLABS == 1 || RT2022_F32_SLABS == 2
                    : table == 1 ? RT2022_F32_SLABS == 2 && !(features & kFeatMisc)
                    : f32_global;

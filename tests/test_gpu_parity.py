@@ -380,6 +380,20 @@ def test_single_precision_slab_test_on_hostile_spheres(rt, O):
         assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), label
 
 
+def test_rect_scenes_keep_the_double_precision_node_test(rt):
+    """A rect lies in the faces of its node's box — where the single-precision test decides nothing: a FEAT-0 scene with
+    rects takes the double-precision kernels, in LDS and in the plain variant alike."""
+    c, g, s, cam, p = golden_case("cornell_box", rt)
+    dev = rt.DeviceScene(s.desc)
+    v = dev.trace_variant()
+    assert v["nodes_in_lds"] == s.desc.n_nodes and not v["f32_slabs"] and not v["spheres_in_lds"], v
+    a = dev.render(cam, p, g["rows"])
+    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24) | (1 << 28))
+    v = dev.trace_variant()
+    assert v["nodes_in_lds"] == 0 and not v["f32_slabs"], v
+    assert np.array_equal(bits(a), bits(dev.render(cam, p, g["rows"]))) and np.array_equal(bits(a), bits(g["rgb_sum"]))
+
+
 def test_scheduling_knobs_never_change_results(rt, O):
     """Segments per traversal workgroup, stream groups, pacing, the timing probe: speed only (rt2022_debug.h)."""
     def word(q=18, reps=1, tail=2, segs=4, shift=2, groups=1, extra=0):
