@@ -243,6 +243,9 @@ def inner_frame(args):
     params = rt.make_params(W, H, spp, 50, bg, seed=args.seed, spp_chunk=args.spp_chunk)
     rows = rt.shuffled_rows(H, args.seed)
     dev = rt.DeviceScene(scene.desc)
+    # (one group of pool segments, like the instrumented call: the counters of a dispatch are then that kernel's alone — with the
+    # library's default of two groups a traversal launch shares the SIMDs with the other group's shade launch)
+    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24))
     out = dev.render(cam, params, rows)
     assert np.isfinite(out).any()
 
@@ -383,8 +386,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--groups", type=int, default=0, help="groups of pool segments passing independently on streams of their own (0: the library's default)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
-    ap.add_argument("--no-plain", action="store_true", help="skip the extra steps without RT_FLAG_KERNEL_TIMES")
+    ap.add_argument("--no-plain", action="store_true", help="(accepted for older scripts; no effect: the timed region IS the plain path now)")
     ap.add_argument("--partial-ring", type=int, default=0,
                     help="planes of the library's partial-sum ring: 0 = its own choice (a ring when all spp planes of a call would exceed 40 % of the device's memory), -1 never, n force")
     ap.add_argument("--frames-per-call", type=int, default=0,
@@ -466,6 +470,8 @@ def main():
     dscene = rt.DeviceScene(scene.desc)
     if args.partial_ring:
         dscene.set_partial_ring(args.partial_ring)
+    if args.groups:
+        dscene.set_tuning(18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (args.groups << 24))
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -515,17 +521,20 @@ def main():
         calls[k] = Call(k)
     main_call = calls[min(fpc, max(args.steps, 1))]
 
+    # The timed region is the PLAIN path — the calls a caller would make: no RT_FLAG_KERNEL_TIMES, the library's own choice of how many
+    # groups of pool segments pass independently (two, on streams of their own, for every scene but the meshes: one group's shade pass
+    # runs beside another's traversal pass). The per-kernel figures the roofline needs come from ONE more call of the same size made
+    # right after it WITH the flag (HIP events around every pass on the launch stream; the flag keeps the pool in one group, so that
+    # a launch's duration is its own): `instrumented_call` in the line.
     for k in split(args.warmup):
-        calls[k].run()
+        calls[k].run(plain=True)
     barrier()
-    kernel_ms, trace_ms, shade_ms, passes = 0.0, 0.0, 0.0, 0
     timed_counts = None
     t0 = time.perf_counter()
     for k in split(args.steps):
         s = F.rt_stats()
-        calls[k].run(s)
-        dscene.wait(stream)          # fills s.ms / s.trace_ms / s.shade_ms from the HIP events on `stream`
-        kernel_ms += s.ms; trace_ms += s.trace_ms; shade_ms += s.shade_ms; passes += s.passes
+        calls[k].run(s, plain=True)
+        dscene.wait(stream)
     barrier()
     elapsed = time.perf_counter() - t0
     # what the timed region did, from the counter passes of its calls
@@ -544,17 +553,19 @@ def main():
         counts = dict(main_call.counts)
     n_steps_counted = max(args.steps, 1) if args.steps else main_call.k
 
-    # The plain path beside it: the timed steps above carry RT_FLAG_KERNEL_TIMES — two HIP events around every pass,
-    # which the roofline needs — so one more call runs without the flag, the way a caller would, and the line reports both.
-    n_plain = 0 if (args.no_plain or not args.steps) else main_call.k
+    # The instrumented call (see above): per-kernel device time and pass pairs of main_call.k steps.
+    n_plain = 0 if not args.steps else main_call.k
     elapsed_plain = 0.0
+    kernel_ms, trace_ms, shade_ms, passes = 0.0, 0.0, 0.0, 0
     if n_plain:
         barrier()
         t0 = time.perf_counter()
-        main_call.run(None, plain=True)
-        dscene.wait(stream)
+        s = F.rt_stats()
+        main_call.run(s, plain=False)
+        dscene.wait(stream)          # fills s.ms / s.trace_ms / s.shade_ms from the HIP events on `stream`
         barrier()
         elapsed_plain = time.perf_counter() - t0
+        kernel_ms, trace_ms, shade_ms, passes = s.ms, s.trace_ms, s.shade_ms, s.passes
 
     t = torch.tensor([elapsed, elapsed_plain], dtype=torch.float64, device=dev)
     cnt = torch.tensor([counts["rays"], counts["paths"], main_call.counts["rays"]], dtype=torch.float64, device=dev)
@@ -571,10 +582,11 @@ def main():
         # per STEP figures of rank 0 (the roofline is about one GPU's kernels): totals of the timed region / steps
         for key, v in list(counts.items()):
             counts[key] = [x / n_steps_counted for x in v] if isinstance(v, list) else (v / n_steps_counted if isinstance(v, (int, float)) else v)
-        k_ms = kernel_ms / n_steps_counted if args.steps else float("nan")
-        tr_ms = trace_ms / n_steps_counted if args.steps else float("nan")
-        sh_ms = shade_ms / n_steps_counted if args.steps else float("nan")
-        n_pass = passes / n_steps_counted if args.steps else 0          # pass pairs per step (a call of fpc steps shares its passes among them)
+        # (per-kernel figures: of the instrumented call, per step of it)
+        k_ms = kernel_ms / n_plain if n_plain else float("nan")
+        tr_ms = trace_ms / n_plain if n_plain else float("nan")
+        sh_ms = shade_ms / n_plain if n_plain else float("nan")
+        n_pass = passes / n_plain if n_plain else 0          # pass pairs per step (a call of fpc steps shares its passes among them)
         n_rows = main_call.n_rows // main_call.k
         ab = algorithmic_bytes(counts, n_rows * W)
         gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else None
@@ -752,10 +764,12 @@ def main():
                                   else "procedural stand-ins (no assets directory)"),
                        "triangles": int(scene.desc.n_triangles), "bvh_nodes": int(scene.desc.n_nodes)},
             "rays_per_step": int(round(total_rays / max(args.steps, 1))), "paths_per_step": int(round(total_paths / max(args.steps, 1))),
-            "plain_path": ({"value": round(plain_rays / elapsed_plain / 1e6, 2), "unit": "Mrays/s", "steps": n_plain,
-                            "ms_per_step": round(elapsed_plain / n_plain * 1e3, 3),
-                            "note": "one more call of the same size without RT_FLAG_KERNEL_TIMES (no HIP events around the passes), run after the timed region; `value` above is the timed region's"}
-                           if n_plain and elapsed_plain > 0 else None),
+            "instrumented_call": ({"value": round(plain_rays / elapsed_plain / 1e6, 2), "unit": "Mrays/s", "steps": n_plain,
+                                   "ms_per_step": round(elapsed_plain / n_plain * 1e3, 3),
+                                   "note": "one more call of the same size WITH RT_FLAG_KERNEL_TIMES, run after the timed region: HIP events around every pass, the pool in one "
+                                           "group (a launch's duration is then its own) — where roofline.device_ms_per_step / launch_ms / launches_per_step come from; "
+                                           "`value` above is the timed region's: the plain calls, no events, the library's own choice of groups"}
+                                  if n_plain and elapsed_plain > 0 else None),
             "roofline": roof,
             "counters_rank0": counts,
         }

@@ -22,7 +22,9 @@ int rt_debug_rng_device(uint64_t state, int mode, double lo, double hi, uint64_t
  *   16-19 pool size of the wavefront engine: segments of 4096 path slots per resident traversal
  *         workgroup (1..8, default 8);
  *   20-23 s: every segment's ray list is ordered longest-first by (expected node steps) >> s, 0 = slot order;
- *   24-27 groups the pool is cut into, each alternating its passes on a stream of its own (1..8, default 1);
+ *   24-27 groups the pool is cut into, each alternating its passes on a stream of its own (1..8; 0, the default: the library's
+ *         choice — two, one for scenes with triangle meshes; RT_FLAG_KERNEL_TIMES, the pass-timing probe and the partial-sum
+ *         ring keep one);
  *   28    keep the BVH's node table out of LDS: the plain traversal kernels even where the node-table variant applies
  *         (rt_debug_trace_variant says which one a scene takes);
  *   29    run the pass-timing probe (rt_debug_pass_timing);

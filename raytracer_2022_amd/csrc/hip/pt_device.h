@@ -241,7 +241,7 @@ hipError_t launch_render_wavefront(const SceneDev &scene, const RenderArgs &args
                                    const WfStreams &gs, hipStream_t stream, uint32_t *out_iterations,
                                    double *timing /* null, or [5]: see rt_debug_pass_timing */,
                                    uint32_t *out_fault /* WfPool::fault after the last pass */,
-                                   KernelTimes *kt /* null, or where to put the per-kernel times (forces one group) */,
+                                   KernelTimes *kt /* null, or where to put the per-kernel times (three HIP events per pass pair on its group's stream) */,
                                    const Progress *progress = nullptr, const RingCtl *ring = nullptr);
 hipError_t launch_chunk_sum(const double *partial, double *out, uint64_t n_values, uint32_t n_chunks, hipStream_t stream);
 // Ring mode: what launch_render_wavefront needs to consume planes as the frame goes.

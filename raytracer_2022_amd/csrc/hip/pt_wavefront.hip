@@ -2213,7 +2213,7 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         }
     }
     const uint32_t trace_blocks = blocks / pool.segs;
-    int G = (timing || kt || ringed) ? 1 : gs.n;
+    int G = (timing || kt || ringed) ? 1 : gs.n;       // (per-kernel times: one group, so that a launch's duration is its own; with several, launches of different groups overlap)
     if (G < 1) G = 1;
     if ((uint32_t)G > trace_blocks) G = (int)trace_blocks;
     WfLaunch w[kMaxGroups];
@@ -2249,19 +2249,21 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
                 if ((e = hipMemsetAsync(pool.dbg, 0xFF, sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
                 if ((e = hipMemsetAsync(pool.dbg + 1, 0, 4 * sizeof(unsigned long long), w[g].stream)) != hipSuccess) return e;
             }
-            // (kernel times: event 2k before the shade pass of pair k, 2k+1 between its shade and trace pass, 2k+2 after)
+            // (kernel times: three events per pass pair k, on the stream of its group — 3k before its shade pass, 3k+1 between its shade
+            // and trace pass, 3k+2 after: with several groups the pairs of different groups overlap, each launch's own duration is what
+            // is summed)
             hipEvent_t mid = nullptr;
             if (kt) {
-                while (kt->ev.size() < 2 * (size_t)iterations + 3) {
+                while (kt->ev.size() < 3 * (size_t)iterations + 3) {
                     hipEvent_t ne = nullptr;
                     if ((e = hipEventCreate(&ne)) != hipSuccess) return e;
                     kt->ev.push_back(ne);
                 }
-                if (iterations == 0 && (e = hipEventRecord(kt->ev[0], w[g].stream)) != hipSuccess) return e;
-                mid = kt->ev[2 * iterations + 1];
+                if ((e = hipEventRecord(kt->ev[3 * iterations], w[g].stream)) != hipSuccess) return e;
+                mid = kt->ev[3 * iterations + 1];
             }
             launch_pass(w[g], iter[g] & 1u, stack_need, features, counters, timing != nullptr, mid);
-            if (kt && (e = hipEventRecord(kt->ev[2 * iterations + 2], w[g].stream)) != hipSuccess) return e;
+            if (kt && (e = hipEventRecord(kt->ev[3 * iterations + 2], w[g].stream)) != hipSuccess) return e;
             iter[g]++;
             iterations++;
         }
@@ -2352,8 +2354,8 @@ static hipError_t render_passes(const SceneDev &scene, const RenderArgs &args, c
         kt->shade_ms = kt->trace_ms = 0.0;
         for (uint32_t k = 0; k < iterations; k++) {
             float a = 0.f, b = 0.f;
-            if ((e = hipEventElapsedTime(&a, kt->ev[2 * k], kt->ev[2 * k + 1])) != hipSuccess) return e;
-            if ((e = hipEventElapsedTime(&b, kt->ev[2 * k + 1], kt->ev[2 * k + 2])) != hipSuccess) return e;
+            if ((e = hipEventElapsedTime(&a, kt->ev[3 * k], kt->ev[3 * k + 1])) != hipSuccess) return e;
+            if ((e = hipEventElapsedTime(&b, kt->ev[3 * k + 1], kt->ev[3 * k + 2])) != hipSuccess) return e;
             kt->shade_ms += (double)a;
             kt->trace_ms += (double)b;
         }

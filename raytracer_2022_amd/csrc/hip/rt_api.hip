@@ -314,7 +314,7 @@ struct rt_scene {
     bool general_boundaries = false;
     bool boxes_plain = false;         // every node box finite with min <= max: the short node step applies
     double split[3] = {0.0, 0.0, 0.0};         // centre of the root's box (list ordering)
-    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(8 * 4096 / kSlotsPerBlock > 0 ? 8 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (1u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 8 segments per resident trace workgroup (4 per CU: 8192 segments = 33.5 M slots); list classes of 4 node steps
+    uint32_t node_quorum = 18u | (1u << 8) | (2u << 12) | ((uint32_t)(8 * 4096 / kSlotsPerBlock > 0 ? 8 * 4096 / kSlotsPerBlock : 1) << 16) | (2u << 20) | (0u << 24);   // fast-path quorum 18 lanes; one extra sphere test per turn; tail factor 2; pool of 8 segments per resident trace workgroup (4 per CU: 8192 segments = 33.5 M slots); list classes of 4 node steps; groups of segments: the library's choice (0)
     uint32_t vote_weights = 0;                 // 0: the engine's own default (kWfVoteWeights / kMegaVoteWeights, pt_device.h)
     int engine = 1;                   // 0 = megakernel, 1 = wavefront (shade / trace passes)
     unsigned long long census_rounds[9] = {}, census_lanes[9] = {};   // of the last counter run
@@ -535,8 +535,12 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         w.pool.segs = segs;
         w.pool.n_cus = (uint32_t)sc->n_cus;
         const bool timing = (sc->node_quorum & (1u << 29)) != 0;
-        w.gs.n = (int)((sc->node_quorum >> 24) & 0xFu);     // groups of segments passing independently (streams)
-        if (w.gs.n < 1) w.gs.n = 1;
+        // Groups of pool segments passing independently, each on a stream of its own: one group's shade pass then runs beside another's
+        // traversal pass and fills what its stragglers leave idle. 0 in the tuning word = the library's choice: two — measured
+        // (profiles/r3ze_groups.log, bench.py --groups): 1e5 random spheres +18 %, Cornell box +3 %, random spheres +1 %, book-2 final
+        // +0.4 % — except for meshes (wwscene: -3 % at two, -7 % at three), which keep one.
+        w.gs.n = (int)((sc->node_quorum >> 24) & 0xFu);
+        if (w.gs.n < 1) w.gs.n = (sc->features & kFeatMisc) ? 1 : 2;
         if (w.gs.n > kMaxGroups) w.gs.n = kMaxGroups;
         w.pool.dbg = timing ? w.pool_dbg : nullptr;
 #if defined(RT2022_SHADE_PROBE) || defined(RT2022_TRACE_PROBE)

@@ -7,14 +7,16 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py "$@" --no-pmc --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err || true
+# (--groups 1: the traced run keeps the pool in one group, like the instrumented call the bench line's launch durations come from — with the
+# library's default of two groups the launches of one group overlap the other's and rocprofv3's averages are those stretched durations)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py "$@" --groups 1 --no-pmc --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.err || true
 python3 - $OUT <<'PY' > $OUT/kernel_stats.txt
 import csv, glob, os, sys, json
 root = sys.argv[1]
 rows = []
 for f in sorted(glob.glob(os.path.join(root, 'trace', '**', '*kernel_stats.csv'), recursive=True)):
     rows += list(csv.DictReader(open(f)))
-print('# rocprofv3 --kernel-trace --stats -- python3 bench.py <args> --no-pmc --no-cpu-baseline')
+print('# rocprofv3 --kernel-trace --stats -- python3 bench.py <args> --groups 1 --no-pmc --no-cpu-baseline')
 for r in rows:
     print('%-110s calls %6s  total %10.3f ms  avg %9.4f ms  %6s %%' % (r['Name'][:110], r['Calls'], float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e6, r['Percentage']))
 try:

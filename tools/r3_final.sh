@@ -10,4 +10,4 @@ timeout -k 10 600 python bench.py > gpurun_out/r3k_bench_default.json 2> gpurun_
 python3 -c "
 import json
 d=json.loads(open('gpurun_out/r3k_bench_default.json').read().strip().splitlines()[-1]); r=d['roofline']
-print(d['metric'], d['value'], d['unit'], d['ms_per_step'], 'steps', d['steps'], 'calls', d['config']['calls'], 'bound', r['bound'], r['frac'], 'sec8d', r['contract_sec8d']['frac'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'plain', d['plain_path']['value'])"
+print(d['metric'], d['value'], d['unit'], d['ms_per_step'], 'steps', d['steps'], 'calls', d['config']['calls'], 'bound', r['bound'], r['frac'], 'sec8d', r['contract_sec8d']['frac'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], 'instrumented call', d['instrumented_call']['value'])"
