@@ -14,8 +14,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      the dominant kernel (wf_trace). bound / achieved / peak / frac = the resource the counters of THIS run show closest to
                 its ceiling — the measured busy share of the vector issue slots, or the HBM bytes of FETCH_SIZE / WRITE_SIZE — with the
                 others ranked beside it (limiter); SURVEY.md §8(d)'s contractual figure (algorithmic bytes per launch / mean launch
-                duration from HIP events over the timed region / 8 TB/s) under contract_sec8d; every figure recomputable from the
-                fields beside it
+                duration from HIP events / 8 TB/s) under contract_sec8d; every figure recomputable from the fields beside it.
+                `value` is the PLAIN path: the timed steps carry no events and the library cuts its pool into its own number of groups
+                (two: one group's shade pass beside another's traversal pass); the per-kernel times come from ONE more call of the same
+                size made right after the timed region with RT_FLAG_KERNEL_TIMES (one group: a launch's duration is its own) —
+                `instrumented_call`
   cpu_baseline  the CPU oracle on a bounded sample of the same workload, at the reference's 8 threads (main.rs:40) and at all usable
                 cores (c1: also the whole frame)
 The PMC figures come from rocprofv3 passes this script runs on itself before it touches the GPU (N=1 only; `--no-pmc` skips them,
