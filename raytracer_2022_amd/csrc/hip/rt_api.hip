@@ -516,6 +516,16 @@ void enqueue(rt_scene *sc, const rt_camera *cam, const rt_params *p, const uint3
         // Use every workgroup slot of the chip even for small jobs (64 paths per workgroup at least).
         uint64_t want = (a.n_items + 63) / 64;
         uint32_t blocks = (uint32_t)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+        // A job of about as many paths as the pool has slots is better served by half the pool: every path starts in the first pass
+        // either way, the passes are as many (a path lives its dozen bounces), and each shade pass sweeps half the segments
+        // (book-1 final 400x225x100, four frames per call — 36 M paths for 33.5 M slots: +11 %, profiles/r3zh_segs.log). Two paths per
+        // slot at least, for jobs large enough to fill the chip anyway; larger jobs keep the whole pool (they lose with a smaller one).
+        {
+            const uint64_t two_per_slot = a.n_items / (2ull * (uint64_t)kSlotsPerBlock);
+            const uint64_t floor_blocks = (uint64_t)kTraceBlocksPerCU * (uint64_t)sc->n_cus * 2ull;      // (never below two segments per resident traversal workgroup)
+            if (sc->max_pool_blocks <= 0 && two_per_slot < blocks && blocks > floor_blocks)
+                blocks = (uint32_t)(two_per_slot > floor_blocks ? two_per_slot : floor_blocks);
+        }
         // (deep paths: keep the bounce tape under 56 GB by taking fewer segments)
         const uint64_t tape_per_block = (uint64_t)kSlotsPerBlock * (p->max_depth ? p->max_depth : 1) * 4 * sizeof(double);
         while (blocks > segs && (uint64_t)blocks * tape_per_block > (56ull << 30)) blocks -= segs;
