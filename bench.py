@@ -389,6 +389,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--quorum", type=int, default=0, help="lanes that must want a node step for the fast path, 1..64 (0: the library's default, 18)")
     ap.add_argument("--segs", type=int, default=0, help="pool size: segments of 4096 path slots per resident traversal workgroup, 1..8 (0: the library's default, 8)")
     ap.add_argument("--groups", type=int, default=0, help="groups of pool segments passing independently on streams of their own (0: the library's default)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes")
@@ -474,8 +475,8 @@ def main():
     dscene = rt.DeviceScene(scene.desc)
     if args.partial_ring:
         dscene.set_partial_ring(args.partial_ring)
-    if args.groups or args.segs:
-        dscene.set_tuning(18 | (1 << 8) | (2 << 12) | ((args.segs or 8) << 16) | (2 << 20) | (args.groups << 24))
+    if args.groups or args.segs or args.quorum:
+        dscene.set_tuning((args.quorum or 18) | (1 << 8) | (2 << 12) | ((args.segs or 8) << 16) | (2 << 20) | (args.groups << 24))
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
