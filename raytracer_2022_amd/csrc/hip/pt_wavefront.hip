@@ -65,7 +65,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RT2022_F32_GLOBAL
-#define RT2022_F32_GLOBAL 1            // the same test on 32-byte single-precision node records from HBM / L2 for the sphere scenes too large for LDS (wf_trace, kF32G)
+#define RT2022_F32_GLOBAL 1            // the same test on 32-byte single-precision node records from HBM / L2 (wf_trace, kF32G): 1 the sphere scenes too large
+                                       // for LDS and the triangle meshes, 2 every instance without boxes / media (A/B, census), 0 none
+#endif
+#ifndef RT2022_STASH
+#define RT2022_STASH 1                 // keep 1/d.x, 1/d.z of the frame a RotateY is entered from (0: two divisions at its exit instead — five registers fewer)
 #endif
 #ifndef RT2022_F32_SLABS
 #define RT2022_F32_SLABS 1             // node table in LDS: single-precision slab test with a double-precision second opinion (wf_trace, t_slabs32):
@@ -1117,7 +1121,13 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
     // two 16-byte loads, from HBM / L2 or, for the first kCache32 of them, from LDS; half the bytes of the double-precision
     // record per node step, and in a partial table 3 045 records instead of 1 740.
-    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : (FEAT == 0 && SPHERES)) && !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+    // ... and for the triangle meshes (FEAT with kFeatMisc, no boxes or media): a triangle touches its box in its corners, one node step
+    // in 1 348 of wwscene is left undecided (its rings lie in the faces of theirs); C5's traversal kernel -3.2 % — once the ten VGPRs the
+    // test needs were found: the RotateY stash is dropped in these instances (two divisions at a RotateY's exit instead; measured alone: no cost).
+    constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 &&
+                           (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : ((FEAT == 0 && SPHERES) || ((FEAT & kFeatMisc) && !(FEAT & kFeatVolumes)))) &&
+                           !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+    constexpr bool kStashInv = RT2022_STASH && !(kF32G && (FEAT & kFeatMovers));
     constexpr int kCache32 = kF32G && CACHE > 0 ? CACHE * 56 / 32 : 0;
     __shared__ f64x2 nc_box[CACHE > 0 && !kF32 && !kF32G ? 3 * CACHE : 1];
     __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 && !kF32G ? CACHE : 1];
@@ -1835,7 +1845,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                 if (rotated) {
                     // 1/d.x, 1/d.z of the frame arrived in: the stash holds them for the frame its RotateY was entered from — this one, or
                     // one whose direction is this one's (only a RotateY changes d); otherwise the two divisions again (same values).
-                    bool stash_ok = L.stash_level != 0xFFFFFFFFu && L.stash_level >= L.ctx.n;
+                    bool stash_ok = kStashInv && L.stash_level != 0xFFFFFFFFu && L.stash_level >= L.ctx.n;
                     for (uint32_t j = L.ctx.n; stash_ok && j < L.stash_level && j < RT_MAX_XFORM_DEPTH; j++)
                         stash_ok = RT_REF_KIND(L.ctx.at(j)) != RT_KIND_ROTATE_Y;
                     if (stash_ok) { L.inv.x = L.stash_ix; L.inv.z = L.stash_iz; }
@@ -1869,7 +1879,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                             const double ox = p1 * L.cur.o.x - p0 * L.cur.o.z, oz = p0 * L.cur.o.x + p1 * L.cur.o.z;
                             const double dx = p1 * L.cur.d.x - p0 * L.cur.d.z, dz = p0 * L.cur.d.x + p1 * L.cur.d.z;
                             L.cur.o.x = ox; L.cur.o.z = oz; L.cur.d.x = dx; L.cur.d.z = dz;
-                            L.stash_ix = L.inv.x; L.stash_iz = L.inv.z; L.stash_level = L.ctx.n;
+                            if (kStashInv) { L.stash_ix = L.inv.x; L.stash_iz = L.inv.z; L.stash_level = L.ctx.n; }
                             L.inv.x = 1.0 / dx; L.inv.z = 1.0 / dz;
                             L.a_len = L.cur.d.length_sqr();
                         } else {                                      // Zoom::hit, mod.rs:321-323: the origin only
@@ -2384,7 +2394,8 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
     out[3] = 0;
     const int table = node_cache_mode(scene, stack_need, tuning, features);
     // Which instances test node boxes in single precision (wf_trace: kF32, kF32G) — bit 1 of out[3]
-    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes) : (RT2022_F32_GLOBAL == 1 && features == 0 && scene.n_rects == 0));
+    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes)
+                            : (RT2022_F32_GLOBAL == 1 && ((features == 0 && scene.n_rects == 0) || ((features & kFeatMisc) && !(features & kFeatVolumes)))));
     const bool f32 = table == 3 ? RT2022_F32_SLABS == 1 || RT2022_F32_SLABS == 2
                    : table == 1 ? RT2022_F32_SLABS == 2 && !(features & kFeatMisc)
                    : f32_global;
