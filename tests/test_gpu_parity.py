@@ -380,6 +380,58 @@ def test_single_precision_slab_test_on_hostile_spheres(rt, O):
         assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref)), label
 
 
+def test_mesh_in_a_partial_node_table(rt, O):
+    """A triangle mesh whose BVH is shallow enough for the node-table kernel (stacks of 16) but larger than the table: the first 3 045
+    nodes as 32-byte single-precision records in LDS, the rest of the same records from L2 / HBM, the double-precision record for
+    the steps the float test leaves undecided — and a quarter of the triangles axis-aligned, lying IN faces of their boxes, where
+    it decides least. Pixels and counters against the oracle."""
+    rng = np.random.default_rng(12)
+    b = rt.DescBuilder()
+    mats = [b.lambertian((0.7, 0.5, 0.4)), b.metal((0.8, 0.8, 0.8), 0.1)]
+    leaves = []
+    n = 4096
+    for i in range(n):
+        c = rng.uniform(-4.0, 4.0, 3) + np.array([0.0, 0.0, -12.0])
+        e1, e2 = rng.uniform(-0.25, 0.25, 3), rng.uniform(-0.25, 0.25, 3)
+        if i % 4 == 0:                                   # an axis-aligned triangle in the plane z = const
+            e1[2] = 0.0; e2[2] = 0.0
+        pa, pb, pc = c, c + e1, c + e2
+        lo = np.minimum(np.minimum(pa, pb), pc) - 1e-4; hi = np.maximum(np.maximum(pa, pb), pc) + 1e-4
+        leaves.append((b.triangle(tuple(pa), tuple(pb), tuple(pc), mats[i % 2]), tuple(lo), tuple(hi)))
+
+    def build(items, axis=0):
+        if len(items) == 1:
+            r, lo, hi = items[0]
+            return b.node(lo, hi, r, r), lo, hi
+        items = sorted(items, key=lambda it: it[1][axis])
+        h = len(items) // 2
+        l, llo, lhi = build(items[:h], (axis + 1) % 3)
+        r, rlo, rhi = build(items[h:], (axis + 1) % 3)
+        lo = tuple(min(a, c_) for a, c_ in zip(llo, rlo)); hi = tuple(max(a, c_) for a, c_ in zip(lhi, rhi))
+        return b.node(lo, hi, l, r), lo, hi
+    root, _, _ = build(leaves)
+    b.set_root(root)
+    d = b.desc()
+    assert d.n_nodes == 2 * n - 1                        # (4 095 inner nodes over a span-1 node per triangle)
+    W, H, spp = 64, 48, 4
+    cam = rt.camera_new((0.0, 0.5, 2.0), (0.0, 0.0, -12.0), (0, 1, 0), 40.0, W / H, 0.0, 10.0, 0.0, 1.0)
+    p = rt.make_params(W, H, spp, 12, (0.7, 0.8, 1.0), seed=21)
+    rows = np.arange(H, dtype=np.uint32)
+    dev = rt.DeviceScene(d)
+    v = dev.trace_variant()
+    assert v["workgroup_threads"] == 1024 and v["nodes_in_lds"] == 1740 * 56 // 32 and v["f32_slabs"], v
+    ref, st_ref = O.render_cpu(d, cam, p, rows, n_threads=4, want_stats=True)
+    out, st = dev.render(cam, p, rows, want_stats=True)
+    assert st.as_dict() == st_ref.as_dict()
+    assert np.array_equal(bits(out), bits(ref))
+    assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref))                   # the timed kernel: partial table, single-precision records
+    assert st_ref.prim_tests[F.RT_KIND_TRIANGLE] > 10_000 and st_ref.rays > W * H * spp
+    dev.set_tuning(18 | (1 << 8) | (2 << 12) | (8 << 16) | (2 << 20) | (1 << 24) | (1 << 28))
+    v = dev.trace_variant()
+    assert v["nodes_in_lds"] == 0 and v["f32_slabs"], v                                # the plain mesh kernel: the same records from L2 / HBM
+    assert np.array_equal(bits(dev.render(cam, p, rows)), bits(ref))
+
+
 def test_rect_scenes_keep_the_double_precision_node_test(rt):
     """A rect lies in the faces of its node's box — where the single-precision test decides nothing: a FEAT-0 scene with
     rects takes the double-precision kernels, in LDS and in the plain variant alike."""
