@@ -1119,20 +1119,19 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
     // (kF32G) The same test for sphere scenes too large for that instance (SPHERES: the plain kernels and the partial-table one):
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
-    // two 16-byte loads, from HBM / L2 or, for the first kCache32 of them, from LDS; half the bytes of the double-precision
-    // record per node step, and in a partial table 3 045 records instead of 1 740.
+    // two 16-byte loads from L2 / HBM: half the bytes of the double-precision record per node step. (These scenes take the plain
+    // kernels even where the partial-table instance would apply: with the first 3 045 of these records in LDS that instance —
+    // four waves per SIMD against the plain kernel's five — measured 10 % slower on the 1e4-sphere scene, node_cache_mode.)
     // ... and for the triangle meshes (FEAT with kFeatMisc, no boxes or media): a triangle touches its box in its corners, one node step
     // in 1 348 of wwscene is left undecided (its rings lie in the faces of theirs); C5's traversal kernel -3.2 % — once the ten VGPRs the
     // test needs were found: the RotateY stash is dropped in these instances (two divisions at a RotateY's exit instead; measured alone: no cost).
     constexpr bool kF32G = RT2022_F32_GLOBAL && RT2022_F32_SLABS >= 1 &&
                            (RT2022_F32_GLOBAL == 2 ? !(FEAT & kFeatVolumes) : ((FEAT == 0 && SPHERES) || ((FEAT & kFeatMisc) && !(FEAT & kFeatVolumes)))) &&
-                           !PRIMS && !STATS && !PROBE && (CACHE == 0 || PARTIAL) && !kF32;
+                           !PRIMS && !STATS && !PROBE && CACHE == 0 && !kF32;
     constexpr bool kStashInv = RT2022_STASH && !(kF32G && (FEAT & kFeatMovers));
-    constexpr int kCache32 = kF32G && CACHE > 0 ? CACHE * 56 / 32 : 0;
     __shared__ f64x2 nc_box[CACHE > 0 && !kF32 && !kF32G ? 3 * CACHE : 1];
     __shared__ u32x2 nc_ref[CACHE > 0 && !kF32 && !kF32G ? CACHE : 1];
     __shared__ uint32_t nc32[kF32 ? kNode32Words * CACHE : 1];
-    __shared__ u32x4 nc32g[kCache32 ? 2 * kCache32 : 1];
     // ... and, in every variant (384 bytes), the first records of the two small tables the arms go to most: movers (32 B
     // each) and media (MediumDev, 64 B each) — two of each in the book-2 final scene.
 #ifndef RT2022_SMALL_TABLES_EVERYWHERE
@@ -1152,13 +1151,8 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     const unsigned lane = tid & 63u;
     Counters<STATS> cnt;
     TStack<STACK, WG> st{stack_lds + tid};
-    constexpr uint32_t kTableRecords = kF32G ? (uint32_t)kCache32 : (uint32_t)CACHE;
-    const uint32_t n_cached = CACHE > 0 ? (s.n_nodes < kTableRecords ? s.n_nodes : kTableRecords) : 0u;
-    if (kCache32) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(s.nodes32);
-        for (uint32_t i = tid; i < 2u * n_cached; i += (uint32_t)WG) nc32g[i] = src[i];
-    }
-    if (CACHE > 0 && !kF32G) {
+    const uint32_t n_cached = CACHE > 0 ? (s.n_nodes < (uint32_t)CACHE ? s.n_nodes : (uint32_t)CACHE) : 0u;
+    if (CACHE > 0) {
         for (uint32_t i = tid; i < n_cached; i += (uint32_t)WG) {
             const f64x2 *np = reinterpret_cast<const f64x2 *>(s.nodes + i);
             f64x2 b0 = np[0], b1 = np[1], b2 = np[2];
@@ -1281,8 +1275,6 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     L.near_at[0] = L.near_at[1] = L.near_at[2] = L.far_at[0] = L.far_at[1] = L.far_at[2] = table_at;
     L.p32[0] = L.p32[1] = L.p32[2] = (f32x2){0.0f, 0.0f}; L.e_ray = __builtin_inff();
     uint32_t refs32_at = table32_at + 36u;                             // (kF32: the child refs of record 0)
-    uint32_t table32g_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) u32x4 *)nc32g;
-    if (kCache32) asm volatile("" : "+v"(table32g_at));
     if (kF32) asm volatile("" : "+v"(refs32_at));
 
     for (;;) {
@@ -1384,19 +1376,10 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
                     // The single-precision test on the 32-byte record (see kF32G above): {min, max} of an axis are one register pair,
                     // one packed multiply-add gives the axis' two slab distances, ordered afterwards (a min and a max per axis —
                     // no per-lane addresses here: one base address serves both loads).
-                    u32x4 q0, q1;
-                    if (kCache32 && nidx < n_cached) {
-                        uint32_t at;
-                        asm("v_lshl_add_u32 %0, %1, 5, %2" : "=v"(at) : "v"(nidx), "v"(table32g_at));
-                        const uint32_t below_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(st.col + below_sp * WG);
-                        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b32 %2, %4\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(q0), "=&v"(q1), "=&v"(below) : "v"(at), "v"(below_at) : "memory");
-                    } else {
-                        const u32x4 *np = reinterpret_cast<const u32x4 *>(s.nodes32) + 2u * (uint64_t)nidx;
-                        q0 = np[0]; q1 = np[1];
-                        below = st.col[below_sp * WG];
-                        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(below));          // (both halves and the stack entry asked for together)
-                    }
+                    const u32x4 *np = reinterpret_cast<const u32x4 *>(s.nodes32) + 2u * (uint64_t)nidx;
+                    u32x4 q0 = np[0], q1 = np[1];
+                    below = st.col[below_sp * WG];
+                    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(below));              // (both halves and the stack entry asked for together)
                     const f32x2 bx = {__uint_as_float(q0.x), __uint_as_float(q0.y)}, by = {__uint_as_float(q0.z), __uint_as_float(q0.w)},
                                 bz = {__uint_as_float(q1.x), __uint_as_float(q1.y)};
                     f32x2 tx, ty, tz;
@@ -1575,7 +1558,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
             }
             if (kF32 && decided) {
                 n0 = n1 = n2 = (f64x2){0.0, 0.0};
-            } else if (CACHE > 0 && !kF32 && !kF32G && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first; kF32G: the voted steps — below the quorum, not plain, or undecided — take the double-precision record from L2)
+            } else if (CACHE > 0 && !kF32 && (!PARTIAL || nidx < n_cached)) {     // (PARTIAL: the table holds the first n_cached nodes — the top of the BVHs, rt_scene_create numbers them breadth-first)
                 n0 = nc_box[3 * nidx]; n1 = nc_box[3 * nidx + 1]; n2 = nc_box[3 * nidx + 2];
                 const u32x2 cr = nc_ref[nidx];
                 n3 = (u32x4){cr.x, 0u, cr.y, 0u};
@@ -2087,13 +2070,6 @@ static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
     const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
     if (grid > most) grid = most;
-    if constexpr (FEAT == 0 && PARTIAL) {
-        if (w.scene.n_rects == 0) {                                   // (a sphere-only scene: single-precision records in the partial table and beyond it)
-            hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL, false, true>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
-                               w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
-            return;
-        }
-    }
     hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
                        w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
 }
@@ -2123,13 +2099,23 @@ static void launch_trace_cached_feat(unsigned feat, const WfLaunch &w, uint32_t 
 // A/B runs, and the test that the two give the same bits.)
 // 0: the plain kernels; 1: the whole table (stacks of 16); 2: its first kNodeCache records (stacks of 16); 3: a
 // sphere-only scene whose node table and sphere pools all fit (RT2022_PRIM_TABLES=0 in the environment: mode 1 instead).
+// The scenes whose plain kernels test node boxes in single precision on SceneDev::nodes32 (wf_trace: kF32G).
+static bool f32_from_hbm(const SceneDev &scene, unsigned features) {
+    return RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes)
+           : (RT2022_F32_GLOBAL == 1 && ((features == 0 && scene.n_rects == 0) || ((features & kFeatMisc) && !(features & kFeatVolumes)))));
+}
 static int node_cache_mode(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, unsigned features) {
     static const bool enabled = [] { const char *e = getenv("RT2022_NODE_CACHE"); return !(e && e[0] == '0'); }();
     static const bool prims = [] { const char *e = getenv("RT2022_PRIM_TABLES"); return !(e && e[0] == '0'); }();
     if (!enabled || (tuning & (1u << 28)) || stack_need > (uint32_t)kStackTiny) return 0;
     if (prims && features == 0 && scene.n_rects == 0 && scene.n_nodes <= (uint32_t)kPrimNodes && scene.n_spheres <= (uint32_t)kPrimSpheres &&
         scene.n_moving_spheres <= (uint32_t)kPrimMoving) return 3;
-    return scene.n_nodes <= (uint32_t)kNodeCache ? 1 : 2;
+    if (scene.n_nodes <= (uint32_t)kNodeCache) return 1;
+    // A scene whose nodes are tested in single precision from 32-byte records (sphere-only, or a triangle mesh: wf_trace, kF32G) takes
+    // the plain kernels when its table does not fit whole: five waves per SIMD there against four here, and half the bytes per node
+    // step either way — the partial table measured 10 % slower (1e4 spheres: 1 854 against 2 039 Mrays/s, profiles/r3zp_partial_vs_plain.log).
+    if (f32_from_hbm(scene, features)) return 0;
+    return 2;
 }
 template <int STACK, bool PROBE = false>
 static void launch_trace_feat(unsigned feat, const WfLaunch &w, uint32_t parity) {
@@ -2394,15 +2380,11 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
     out[3] = 0;
     const int table = node_cache_mode(scene, stack_need, tuning, features);
     // Which instances test node boxes in single precision (wf_trace: kF32, kF32G) — bit 1 of out[3]
-    const bool f32_global = RT2022_F32_SLABS >= 1 && (RT2022_F32_GLOBAL == 2 ? !(features & kFeatVolumes)
-                            : (RT2022_F32_GLOBAL == 1 && ((features == 0 && scene.n_rects == 0) || ((features & kFeatMisc) && !(features & kFeatVolumes)))));
     const bool f32 = table == 3 ? RT2022_F32_SLABS == 1 || RT2022_F32_SLABS == 2
                    : table == 1 ? RT2022_F32_SLABS == 2 && !(features & kFeatMisc)
-                   : f32_global;
+                   : table == 0 ? f32_from_hbm(scene, features) : false;
     if (table) {
-        // (a partial table under kF32G holds 32-byte single-precision records)
-        const uint32_t cap = (table == 2 && f32_global) ? (uint32_t)kNodeCache * 56u / 32u : (uint32_t)kNodeCache;
-        out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < cap ? scene.n_nodes : cap;
+        out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < (uint32_t)kNodeCache ? scene.n_nodes : (uint32_t)kNodeCache;
         out[3] = (table == 3 ? 1u : 0u) | (f32 ? 2u : 0u);
         return;
     }
