@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // Cornell box's 6 % slower, whether the undecided lanes fetch the double-precision box on the spot or hand the step to the
     // voted arm (profiles/r3q_ab_f32_slabs.log).
     constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
-    // (kF32G) The same test for sphere scenes too large for that instance (SPHERES: the plain kernels and the partial-table one):
+    // (kF32G) The same test in the plain kernels, for sphere scenes too large for that instance (SPHERES):
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
     // two 16-byte loads from L2 / HBM: half the bytes of the double-precision record per node step. (These scenes take the plain
     // kernels even where the partial-table instance would apply: with the first 3 045 of these records in LDS that instance —
