@@ -1116,7 +1116,9 @@ __global__ void __launch_bounds__(WG, trace_waves_per_simd(STACK, STATS, FEAT, W
     // (tools/f32_census.py) — measured, the random spheres' traversal kernel 6-7 % faster, the final scene's 1 % and the
     // Cornell box's 6 % slower, whether the undecided lanes fetch the double-precision box on the spot or hand the step to the
     // voted arm (profiles/r3q_ab_f32_slabs.log).
-    constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc)) : (RT2022_F32_SLABS == 1 && PRIMS);
+    // (... and the whole-table instance of the sphere-only scenes too large for the all-in-LDS one: 601 to 1 740 nodes.)
+    constexpr bool kF32 = RT2022_F32_SLABS == 2 ? (CACHE > 0 && !PARTIAL && !(FEAT & kFeatMisc))
+                                                : (RT2022_F32_SLABS == 1 && (PRIMS || (SPHERES && FEAT == 0 && CACHE > 0 && !PARTIAL)));
     // (kF32G) The same test in the plain kernels, for sphere scenes too large for that instance (SPHERES):
     // 32-byte single-precision records {min.x, max.x, min.y, max.y | min.z, max.z, left, push ref} — SceneDev::nodes32 — fetched as
     // two 16-byte loads from L2 / HBM: half the bytes of the double-precision record per node step. (These scenes take the plain
@@ -2070,6 +2072,13 @@ static void launch_trace_cached(const WfLaunch &w, uint32_t parity) {
     uint32_t grid = w.pool.n_cus ? w.pool.n_cus : 1u;
     const uint32_t most = std::max(1u, w.blocks * ((uint32_t)S / kChunk) / (uint32_t)(kCacheBlock / 64));
     if (grid > most) grid = most;
+    if constexpr (FEAT == 0 && !PARTIAL) {
+        if (w.scene.n_rects == 0) {                                   // (a sphere-only scene: the single-precision records of t_slabs32 in the table)
+            hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL, false, true>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
+                               w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
+            return;
+        }
+    }
     hipLaunchKernelGGL((wf_trace<STACK, false, FEAT, false, kCacheBlock, CACHE, PARTIAL>), dim3(grid), dim3(kCacheBlock), 0, w.stream,
                        w.scene, w.pool, w.t_min, w.node_quorum, parity, w.stats, w.vote_weights);
 }
@@ -2381,7 +2390,7 @@ void trace_variant(const SceneDev &scene, uint32_t stack_need, uint32_t tuning, 
     const int table = node_cache_mode(scene, stack_need, tuning, features);
     // Which instances test node boxes in single precision (wf_trace: kF32, kF32G) — bit 1 of out[3]
     const bool f32 = table == 3 ? RT2022_F32_SLABS == 1 || RT2022_F32_SLABS == 2
-                   : table == 1 ? RT2022_F32_SLABS == 2 && !(features & kFeatMisc)
+                   : table == 1 ? (RT2022_F32_SLABS == 2 && !(features & kFeatMisc)) || (RT2022_F32_SLABS == 1 && features == 0 && scene.n_rects == 0)
                    : table == 0 ? f32_from_hbm(scene, features) : false;
     if (table) {
         out[0] = (uint32_t)kCacheBlock; out[1] = (uint32_t)kStackTiny; out[2] = scene.n_nodes < (uint32_t)kNodeCache ? scene.n_nodes : (uint32_t)kNodeCache;

@@ -725,6 +725,16 @@ def test_node_table_variant_gives_the_same_bits(rt):
         assert v2["nodes_in_lds"] == 0 and v2["workgroup_threads"] == 256, (name, v2)
         b = dev.render(cam, p, g["rows"])
         assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(g["rgb_sum"])), name
+    # A sphere-only scene too large for the all-in-LDS instance whose table still fits (601 to 1 740 nodes): single-precision records in LDS
+    mid = rt.HostScene("random_scene", seed=5, param=12)             # (25 x 25 grid: ~740 nodes)
+    dev = rt.DeviceScene(mid.desc)
+    v = dev.trace_variant()
+    assert v["workgroup_threads"] == 1024 and v["nodes_in_lds"] == mid.desc.n_nodes and v["f32_slabs"] and not v["spheres_in_lds"], v
+    cam, bg = mid.default_view(16 / 9)
+    p = rt.make_params(64, 36, 3, 50, bg, seed=5)
+    rows = np.arange(36, dtype=np.uint32)
+    from oracle import oracle_ffi as O_
+    assert np.array_equal(bits(dev.render(cam, p, rows)), bits(O_.render_cpu(mid.desc, cam, p, rows, n_threads=4)))
     # A sphere scene whose node table does not fit takes the plain kernel — single-precision 32-byte node records from L2 / HBM, five
     # waves per SIMD — not the partial table (measured: 10 % slower there).
     big = rt.HostScene("random_scene", seed=5, param=40)             # (81 x 81 grid: ~13 K nodes)
@@ -735,7 +745,6 @@ def test_node_table_variant_gives_the_same_bits(rt):
     p = rt.make_params(64, 36, 2, 50, bg, seed=5)
     rows = np.arange(36, dtype=np.uint32)
     a = dev.render(cam, p, rows)
-    from oracle import oracle_ffi as O_
     assert np.array_equal(bits(a), bits(O_.render_cpu(big.desc, cam, p, rows, n_threads=4)))
     # ... and a BVH too deep for stacks of 16 entries takes the plain kernels
     deep = rt.HostScene("wwscene", seed=5, param=1)
